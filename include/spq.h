@@ -1,0 +1,144 @@
+/*
+ * spq.h -- C ABI of libspq.so: the MI355X (gfx950) implementation of the fake-quantized linear hot path
+ * of Laurence-Wu/LLM-QAT-on-gpt2 (SPLinearWithLoRA.forward and everything it calls).
+ *
+ * The reference is pure Python and has no FFI layer; this header is the boundary a
+ * maintainer binds with ctypes.  Each entry point names the reference code it
+ * replaces (paths relative to part1_switchable_precision/).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (torch: tensor.data_ptr()); no ownership
+ *     transfer, no hidden allocation, no host synchronisation; work is enqueued on `stream` (hipStream_t
+ *     passed as void*; NULL = the null stream).
+ *   - tensors are fp32, row-major, contiguous unless a leading dimension is given.
+ *   - return value: 0 on success, a negative SPQ_ERR_* otherwise; spq_last_error() gives the message of the
+ *     calling thread's last failure.
+ *   - functions keep no state; they are safe to call from several threads on different streams.
+ */
+#ifndef SPQ_H
+#define SPQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPQ_VERSION 100 /* 0.1.0 */
+
+enum spq_status {
+  SPQ_OK = 0,
+  SPQ_ERR_INVALID = -1,     /* bad argument (null pointer, non-positive size, unsupported bit-width ...) */
+  SPQ_ERR_LAUNCH = -2,      /* HIP reported an error at launch */
+  SPQ_ERR_UNSUPPORTED = -3, /* valid request this build has no kernel for */
+  SPQ_ERR_DEVICE = -4,      /* no gfx950 device / wrong architecture */
+  SPQ_ERR_WORKSPACE = -5    /* workspace too small or misaligned */
+};
+
+enum spq_qtype { SPQ_MINMAX = 0, SPQ_LOG = 1 };
+
+/* GEMM operand paths of spq_linear_lora_fwd (see DESIGN.md "Kernels") */
+enum spq_path {
+  SPQ_PATH_AUTO = 0,
+  SPQ_PATH_F32 = 1,   /* fp32-input MFMA on dequantised fp32 operands: always valid */
+  SPQ_PATH_F16X2 = 2  /* exact integer levels (fp16) x 2-limb fp16 weights on f16 MFMA: minmax, symmetric, bits<=12 */
+};
+
+typedef void* spq_stream_t;
+
+int spq_version(void);
+const char* spq_last_error(void);
+/* Writes the gcnArchName of the current device ("gfx950:sramecc+:xnack-") into buf. */
+int spq_device_arch(char* buf, int buflen);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Calibration statistics.  Replaces LearnableFakeQuantize._collect_statistics_batch +
+ * _get_reduction_dims + _reduce_min_max (quantization.py:141-209).
+ *
+ * x is viewed as [outer, chan, inner]; the statistic keeps `chan` (per_channel=1) or reduces everything
+ * (per_channel=0, then min_io/max_io hold 1 value).  log_domain=0: running min/max of x.
+ * log_domain=1: running min/max of log2(clamp(|x|, eps)), skipped when no element has |x| > eps, except
+ * that a first batch without such an element fills both with log_eps_fill (= fp32 log2(eps), :194-197).
+ * first_batch!=0 assigns, otherwise merges (minimum/maximum) into min_io/max_io, in place.
+ * workspace: spq_stats_workspace_bytes() bytes, 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------- */
+size_t spq_stats_workspace_bytes(int64_t outer, int64_t chan, int64_t inner, int per_channel);
+int spq_minmax_stats(const float* x, int64_t outer, int64_t chan, int64_t inner, int per_channel,
+                     int log_domain, float eps, float log_eps_fill, int first_batch, float* min_io,
+                     float* max_io, void* workspace, size_t workspace_bytes, spq_stream_t stream);
+
+/* running min/max -> scale / zero_point.  Replaces LearnableFakeQuantize.finish_calibration
+ * (quantization.py:104-139).  minmax symmetric: scale = clamp(max(|min|,|max|), eps)/(2^(b-1)-1), zp = 0;
+ * minmax asymmetric: scale = clamp(max-min, eps)/(2^b-1), zp = round(-min/scale);
+ * log: scale = max-min (log range), zp = min (log min). */
+int spq_finish_scale(const float* rmin, const float* rmax, int64_t len, int bits, int qtype, int symmetric,
+                     float eps, float* scale_out, float* zp_out, spq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Standalone quantize-dequantize.  Replaces MinMaxQuantizationFunction.forward
+ * (quantization_methods.py:8-22) and LogQuantizationFunction.forward (:33-79; for qtype=SPQ_LOG
+ * `scale` is the log range and `zp` the log min, the argument order of quantization.py:237-239).
+ *
+ * x viewed as [outer, chan, inner]; scale/zp have `chan` entries (per_channel=1) or 1 entry.
+ * out_f32 (nullable): dequantised values, same shape as x.  out_levels (nullable): the integer levels
+ * before dequantisation, as int8/int16/int32 (levels_bytes = 1, 2 or 4).
+ * transpose_out!=0 (requires outer==1... i.e. a 2-D [chan, inner] or [outer, chan] view): out_f32 is
+ * written transposed, used to lay LoRA factors out K-contiguous for the GEMM.
+ * ------------------------------------------------------------------------------------------------- */
+int spq_fakequant(const float* x, int64_t outer, int64_t chan, int64_t inner, const float* scale,
+                  const float* zp, int per_channel, int bits, int qtype, int symmetric, float* out_f32,
+                  void* out_levels, int levels_bytes, spq_stream_t stream);
+
+/* out[c, r] = fakequant(x)[r, c] for a 2-D x[rows, cols] whose scale is per column (chan = cols,
+ * per_channel=1) or per tensor; the layout the GEMM wants for LoRA factors (lora.py:39-40,49-50). */
+int spq_fakequant_transposed(const float* x, int64_t rows, int64_t cols, const float* scale,
+                             const float* zp, int per_channel, int bits, int qtype, int symmetric,
+                             float out_scaling, float* out_f32, spq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Dense contraction on fp32-input MFMA (v_mfma_f32_32x32x2_f32), "NT" layout:
+ *   C[m, n] = sum_k A[m,k] * B[n,k]  + bias[n]  + alpha2 * sum_j A2[m,j] * B2[n,j]
+ * bias, A2/B2 nullable (K2 = 0).  Replaces F.linear (lora.py:144) and the two torch.matmul of
+ * LoRALayer.forward (lora.py:51-52).  Leading dimensions in elements.
+ * ------------------------------------------------------------------------------------------------- */
+int spq_gemm_f32_nt(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t K, const float* A2,
+                    int64_t lda2, const float* B2, int64_t ldb2, int64_t K2, float alpha2,
+                    const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, spq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * The fused forward.  Replaces SPLinearWithLoRA.forward for current_bits < 32 (lora.py:133-150):
+ *   y = FQ_x(x) . FQ_w(W)^T + bias + scaling * (x . FQ_A(A)) . FQ_B(B)        (LoRA on the RAW x)
+ * from operands prepared once per (weights, scales) by spq_prepare_* below.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct spq_fwd_args {
+  /* problem */
+  int64_t M, K, N, r;          /* r = 0: no LoRA branch (calibration_mode or disabled adapter) */
+  int bits, qtype, symmetric;  /* of the INPUT quantizer */
+  int quantize_input;          /* 0: x is used as is (input quantizer collecting statistics) */
+  int x_per_channel;           /* sx/zx have K entries (1) or one entry (0) */
+  int path;                    /* enum spq_path actually prepared for */
+  /* activations */
+  const float* x;              /* [M, K] */
+  const float* sx;             /* input scale (log: range) */
+  const float* zx;             /* input zero point (log: min) */
+  /* prepared operands (spq_prepare_*) */
+  const void* w_prep;          /* F32: fp32 FQ(W) [N,K];  F16X2: hi/lo limb planes */
+  const float* w_rowscale;     /* F16X2: per-row power-of-two descale [N]; else NULL */
+  const float* bias;           /* [N] or NULL */
+  const float* a_prep;         /* fp32 FQ(A)^T [r, K] */
+  const void* b_prep;          /* F32: fp32 scaling*FQ(B)^T [N, r]; F16X2: limb planes */
+  float lora_scaling;          /* alpha / rank, applied where b_prep does not already carry it */
+  /* output + scratch */
+  float* y;                    /* [M, N] */
+  void* workspace;
+  size_t workspace_bytes;
+} spq_fwd_args;
+
+size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path);
+int spq_linear_lora_fwd(const spq_fwd_args* args, spq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPQ_H */

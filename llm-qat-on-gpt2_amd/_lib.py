@@ -1,0 +1,122 @@
+"""ctypes binding of libspq.so (the C ABI declared in include/spq.h).
+
+There is NO CPU fallback: if the library is missing, or a tensor is not on a gfx950 device, the calls below
+raise.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` (or ``make -C llm-qat-on-gpt2_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspq.so")
+
+MINMAX, LOG = 0, 1
+PATH_AUTO, PATH_F32, PATH_F16X2 = 0, 1, 2
+QTYPE_CODE = {"minmax": MINMAX, "log": LOG}
+
+_lib = None
+_p = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+_f = C.c_float
+_sz = C.c_size_t
+
+
+class FwdArgs(C.Structure):
+    """struct spq_fwd_args (include/spq.h)."""
+    _fields_ = [("M", _i64), ("K", _i64), ("N", _i64), ("r", _i64),
+                ("bits", _int), ("qtype", _int), ("symmetric", _int), ("quantize_input", _int),
+                ("x_per_channel", _int), ("path", _int),
+                ("x", _p), ("sx", _p), ("zx", _p),
+                ("w_prep", _p), ("w_rowscale", _p), ("bias", _p), ("a_prep", _p), ("b_prep", _p),
+                ("lora_scaling", _f),
+                ("y", _p), ("workspace", _p), ("workspace_bytes", _sz)]
+
+
+# name -> (restype, argtypes); must list every symbol include/spq.h declares (tests/test_cabi.py checks).
+SIGNATURES = {
+    "spq_version": (_int, []),
+    "spq_last_error": (C.c_char_p, []),
+    "spq_device_arch": (_int, [C.c_char_p, _int]),
+    "spq_stats_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
+    "spq_minmax_stats": (_int, [_p, _i64, _i64, _i64, _int, _int, _f, _f, _int, _p, _p, _p, _sz, _p]),
+    "spq_finish_scale": (_int, [_p, _p, _i64, _int, _int, _int, _f, _p, _p, _p]),
+    "spq_fakequant": (_int, [_p, _i64, _i64, _i64, _p, _p, _int, _int, _int, _int, _p, _p, _int, _p]),
+    "spq_fakequant_transposed": (_int, [_p, _i64, _i64, _p, _p, _int, _int, _int, _int, _f, _p, _p]),
+    "spq_gemm_f32_nt": (_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _f, _p, _p, _i64, _i64, _i64, _p]),
+    "spq_fwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int]),
+    "spq_linear_lora_fwd": (_int, [C.POINTER(FwdArgs), _p]),
+}
+
+
+class SpqError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libspq.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"libspq.so not found at {LIB_PATH}: the HIP extension is not built and there is no CPU fallback. "
+            "Run `python -c \"import __graft_entry__ as g; g.build()\"` at the repo root.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().spq_last_error().decode("utf-8", "replace")
+        raise SpqError(f"{what} failed with code {rc}: {msg}")
+
+
+def require_gpu(t: torch.Tensor, what: str = "tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"llm_qat_on_gpt2_amd: {what} is on '{t.device}'. The fake-quant path runs only as HIP kernels on a "
+            "gfx950 (MI355X) device; there is no CPU fallback.")
+    if t.dtype != torch.float32:
+        raise TypeError(f"llm_qat_on_gpt2_amd: {what} must be float32, got {t.dtype}")
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+_arch_checked = set()
+
+
+def check_device(device):
+    """Once per device: the library is gfx950-only."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _arch_checked:
+        return
+    with torch.cuda.device(idx):
+        buf = C.create_string_buffer(128)
+        check(load().spq_device_arch(buf, 128), "spq_device_arch")
+    _arch_checked.add(idx)
+
+
+_workspaces = {}
+
+
+def workspace(device, nbytes: int) -> torch.Tensor:
+    """One grow-only scratch buffer per (device, stream); calls on one stream serialise, so layers share it."""
+    key = (device.index, stream_ptr(device))
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

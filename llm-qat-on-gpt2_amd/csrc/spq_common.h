@@ -1,0 +1,110 @@
+// Shared device helpers and host-side error plumbing for libspq (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/spq.h"
+
+namespace spq {
+
+// ---- host: thread-local error message ----------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define SPQ_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::spq::set_error(__VA_ARGS__);      \
+      return SPQ_ERR_INVALID;             \
+    }                                     \
+  } while (0)
+
+__host__ __device__ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device: the quantization arithmetic, op for op as the reference --------------------------------
+// This translation unit set is compiled with -ffp-contract=off: every multiply, add and divide below is
+// its own IEEE-754 round-to-nearest operation, like the ATen CPU kernels the reference runs on.
+
+// torch.round == round-half-to-even == rintf under the default rounding mode.
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// quantization_methods.py:14-15 / :18-19 -- integer level (held in fp32)
+template <bool SYM>
+__device__ __forceinline__ float minmax_level(float x, float scale, float zp, float qlo, float qhi) {
+  float q = SYM ? rintf(x / scale) : rintf(x / scale + zp);
+  return clampf(q, qlo, qhi);
+}
+// :16 / :20
+template <bool SYM>
+__device__ __forceinline__ float minmax_dequant(float q, float scale, float zp) {
+  return SYM ? q * scale : (q - zp) * scale;
+}
+
+// fp32 log2 / exp2 via fp64 (correctly rounded in all but ~1e-7 of cases); ATen's CPU log2f/powf are
+// <=1-ulp SLEEF kernels, so a last-bit difference is possible there, see DESIGN.md "log path".
+__device__ __forceinline__ float log2_rn(float v) { return (float)log2((double)v); }
+__device__ __forceinline__ float exp2_rn(float v) { return (float)exp2((double)v); }
+
+struct LogParams {
+  float n2;     // 2*n (sym) or n (asym): the multiplier before rounding
+  float qlo, qhi;
+  float full;   // 2^b - 1
+  float denom;  // sym: 2*n ; asym: n
+};
+
+__host__ __device__ inline LogParams make_log_params(int bits, bool sym) {
+  LogParams p;
+  if (sym) {
+    float n = (float)((1 << (bits - 1)) - 1);
+    p.n2 = n;  // applied as (c*2)*n like the reference, see log_level
+    p.qlo = -n; p.qhi = n;
+    p.denom = 2.0f * n;
+  } else {
+    float n = (float)((1u << bits) - 1u);
+    p.n2 = n; p.qlo = 0.f; p.qhi = n; p.denom = n;
+  }
+  p.full = (float)((1u << bits) - 1u);
+  return p;
+}
+
+// quantization_methods.py:45-61 -> integer level
+template <bool SYM>
+__device__ __forceinline__ float log_level(float x, float log_min, float log_range, const LogParams& p) {
+  const float eps = 1e-5f;                                         // :35 (hard-coded)
+  float mag = fmaxf(fabsf(x), eps);                                // :45
+  float lg = log2_rn(mag);                                         // :47
+  float ln = (lg - log_min) / fmaxf(log_range, eps);               // :49
+  ln = clampf(ln, 0.f, 1.f);                                       // :50
+  float pre;
+  if (SYM) pre = ((ln - 0.5f) * 2.0f) * p.n2;                      // :54-55  centered * 2 * n_levels
+  else     pre = ln * p.n2;                                        // :60
+  return clampf(rintf(pre), p.qlo, p.qhi);                         // :55-56 / :60-61
+}
+// :57,:64-74 -> dequantised value
+template <bool SYM>
+__device__ __forceinline__ float log_dequant(float x, float q, float log_min, float log_range,
+                                             const LogParams& p) {
+  float qn;
+  if (SYM) qn = ((q / p.denom + 0.5f) * p.full) / p.full;          // :57 then :64
+  else     qn = q / p.denom;                                       // :66
+  float x_hat = qn * log_range + log_min;                          // :68 (unclamped range)
+  float mag = exp2_rn(x_hat);                                      // :70
+  float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);          // :43
+  float out = mag * sgn;                                           // :72
+  return (fabsf(x) < 1e-5f) ? 0.f : out;                           // :41,:74
+}
+
+// 64-lane butterfly reductions (wavefront = 64 on gfx950)
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace spq

@@ -1,0 +1,288 @@
+"""``LoRALayer`` and ``SPLinearWithLoRA`` on the fused HIP forward.
+
+Host-side mirror of the reference's ``part1_switchable_precision/lora.py:13-150`` (``part5_squad/lora.py`` is an
+identical copy): same constructors, attribute names, ``ModuleDict`` keys (``'{b}bit'``), buffers and state-dict
+layout, so the classes drop into ``models_sp.py`` unchanged.  ``forward`` enqueues ``spq_linear_lora_fwd``
+(include/spq.h) instead of ~20 ATen kernels; the weight-side operands FQ(W), FQ(A), FQ(B) are prepared once per
+(weights, scales) instead of on every call (lora.py:142, :49-50 recompute them each forward; same values).
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .fake_quantize import LearnableFakeQuantize
+
+
+class LoRALayer(nn.Module):
+    """Low-rank adapter with fake-quantised factors (lora.py:13-54)."""
+
+    def __init__(self, in_features, out_features, rank, alpha, bits, quantizer_type, eps=1e-5, per_channel=True):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.rank = rank
+        self.alpha = alpha
+        self.bits = bits
+        self.enabled = not (bits >= 32 or rank <= 0)
+        if not self.enabled:
+            self.scaling = 0
+            self.register_buffer('lora_A', torch.zeros(1, 1))
+            self.register_buffer('lora_B', torch.zeros(1, 1))
+            self.quantize_A = None
+            self.quantize_B = None
+            return
+        self.scaling = alpha / rank
+        self.lora_A = nn.Parameter(torch.zeros(in_features, rank))
+        self.lora_B = nn.Parameter(torch.zeros(rank, out_features))
+        nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))
+        nn.init.zeros_(self.lora_B)
+        common = dict(num_bits=bits, quantizer_type=quantizer_type, channel_dim=1, eps=eps, per_channel=per_channel)
+        self.quantize_A = LearnableFakeQuantize(**common)
+        self.quantize_B = LearnableFakeQuantize(**common)
+        # never written by the reference either, but present in every state_dict (lora.py:42-43)
+        self.register_buffer('lora_A_quantized', torch.empty(in_features, rank))
+        self.register_buffer('lora_B_quantized', torch.empty(rank, out_features))
+
+    def forward(self, x):
+        """Stand-alone adapter output ((x @ FQ(A)) @ FQ(B)) * scaling, lora.py:45-54.  SPLinearWithLoRA does not
+        call this in its fused forward; it is here for callers that use the adapter on its own and for autograd."""
+        if not self.enabled or self.scaling == 0:
+            return torch.zeros(*x.shape[:-1], self.out_features, device=x.device, dtype=x.dtype)
+        a_q = self.quantize_A(self.lora_A)
+        b_q = self.quantize_B(self.lora_B)
+        if torch.is_grad_enabled() and (x.requires_grad or self.lora_A.requires_grad or self.lora_B.requires_grad):
+            return torch.matmul(torch.matmul(x, a_q), b_q) * self.scaling
+        _lib.require_gpu(x, "LoRA input")
+        x2 = x.contiguous().view(-1, self.in_features)
+        y = _gemm_nt(_gemm_nt(x2, a_q.t().contiguous()), b_q.t().contiguous())
+        return (y * self.scaling).view(*x.shape[:-1], self.out_features)
+
+
+def _gemm_nt(a, b_nk, bias=None):
+    """a[M,K] . b[N,K]^T on the fp32 MFMA kernel (spq_gemm_f32_nt)."""
+    M, K = a.shape
+    N = b_nk.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        rc = _lib.load().spq_gemm_f32_nt(a.data_ptr(), K, b_nk.data_ptr(), K, K, None, 0, None, 0, 0, 1.0,
+                                         _lib.ptr(bias), out.data_ptr(), N, M, N, _lib.stream_ptr(a.device))
+    _lib.check(rc, "spq_gemm_f32_nt")
+    return out
+
+
+class _Prepared:
+    """Weight-side GEMM operands of one bit-width plus the signature of what they were built from."""
+    __slots__ = ("sig", "path", "w", "w_rowscale", "a", "b", "r")
+
+    def __init__(self):
+        self.sig = None
+
+
+def _sig(t):
+    return (t.data_ptr(), t._version, tuple(t.shape))
+
+
+class SPLinearWithLoRA(nn.Module):
+    """Switchable-precision linear layer: one frozen fp32 weight, per-bit-width quantizers and adapters
+    (lora.py:56-150)."""
+
+    def __init__(self, in_features, out_features, bit_widths, lora_rank_per_bit, lora_alpha_per_bit,
+                 quantizer_per_bit, eps=1e-5, per_channel=True):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.bit_widths = bit_widths
+        self.lora_rank_per_bit = lora_rank_per_bit
+        student_bits = [b for b in bit_widths if b < 32]
+        self.current_bits = sorted(bit_widths, reverse=True)[1]     # second-largest width (lora.py:71)
+
+        self.linear = nn.Linear(in_features, out_features, bias=True)
+
+        def quantizer(bits, channel_dim, **kw):
+            return LearnableFakeQuantize(num_bits=bits, quantizer_type=quantizer_per_bit[bits],
+                                         channel_dim=channel_dim, eps=eps, per_channel=per_channel, **kw)
+
+        self.quantizers_weight = nn.ModuleDict({f'{b}bit': quantizer(b, 0) for b in student_bits})
+        self.quantizers_input = nn.ModuleDict({f'{b}bit': quantizer(b, -1, is_input=True) for b in student_bits})
+        self.lora_adapters = nn.ModuleDict({
+            f'{b}bit': LoRALayer(in_features, out_features, rank=lora_rank_per_bit[b], alpha=lora_alpha_per_bit[b],
+                                 bits=b, quantizer_type=quantizer_per_bit[b], eps=eps, per_channel=per_channel)
+            for b in student_bits})
+
+        self.register_buffer('weight_quantized', torch.empty(out_features, in_features))
+        self.register_buffer('input_quantized', None)
+        self.calibration_mode = False
+
+        # --- not part of the reference surface -----------------------------------------------------------
+        self.operand_path = _lib.PATH_AUTO        # enum spq_path; AUTO picks the fastest valid one
+        self.cache_operands = True                # reuse prepared operands in eval mode (see _operands)
+        self._prepared = {}
+
+    # ---- precision switching (lora.py:105-125): attribute flips only ---------------------------------------
+    def set_precision(self, bits) -> int:
+        if bits >= 32:
+            self.current_bits = 32
+            return bits
+        self.current_bits = bits
+        key = f'{bits}bit'
+        self.quantizers_weight[key].set_num_bits(bits)
+        self.quantizers_input[key].set_num_bits(bits)
+        lora = self.lora_adapters[key]
+        if lora.quantize_A is not None:
+            lora.quantize_A.set_num_bits(bits)
+        if lora.quantize_B is not None:
+            lora.quantize_B.set_num_bits(bits)
+        return self.current_bits
+
+    def get_active_lora(self):
+        return self.lora_adapters[f'{self.current_bits}bit']
+
+    def invalidate_operand_cache(self):
+        """Drop prepared operands (needed only after writing weights through ``.data`` in eval mode)."""
+        self._prepared.clear()
+
+    # ---- forward (lora.py:127-150) ---------------------------------------------------------------------------
+    def forward(self, x):
+        if self.current_bits >= 32:
+            return F.linear(x, self.linear.weight, self.linear.bias)
+        key = f'{self.current_bits}bit'
+        if key not in self.quantizers_weight or key not in self.quantizers_input:
+            raise KeyError(f"No weight quantizer for {key}")
+        qw, qx, lora = self.quantizers_weight[key], self.quantizers_input[key], self.lora_adapters[key]
+
+        needs_grad = torch.is_grad_enabled() and (
+            x.requires_grad or self.linear.weight.requires_grad
+            or (self.linear.bias is not None and self.linear.bias.requires_grad)
+            or (lora.enabled and not self.calibration_mode and (lora.lora_A.requires_grad or lora.lora_B.requires_grad)))
+        if needs_grad or qw.collecting_stats or (lora.enabled and (lora.quantize_A.collecting_stats or lora.quantize_B.collecting_stats)):
+            return self._forward_composed(x, qx, qw, lora)
+        return self._forward_fused(x, key, qx, qw, lora)
+
+    def _forward_composed(self, x, qx, qw, lora):
+        """Autograd-capable composition: HIP fake-quant kernels with straight-through backward, GEMMs by
+        torch-ROCm.  Used only when a gradient is required (training; SURVEY.md §8 f2 is the fused backward)."""
+        base = F.linear(qx(x), qw(self.linear.weight), self.linear.bias)
+        if self.calibration_mode:
+            return base
+        return base + lora(x)
+
+    def _forward_fused(self, x, key, qx, qw, lora):
+        _lib.require_gpu(x, "SPLinearWithLoRA input")
+        _lib.check_device(x.device)
+        W = self.linear.weight
+        if W.device != x.device:
+            raise RuntimeError(f"SPLinearWithLoRA: weight on {W.device}, input on {x.device}")
+        if x.shape[-1] != self.in_features:
+            raise RuntimeError(f"SPLinearWithLoRA: input has {x.shape[-1]} features, expected {self.in_features}")
+        quantize_input = 1
+        if qx.num_bits >= 32:
+            quantize_input = 0
+        elif qx.collecting_stats:                      # quantization.py:214-216: record, pass x through
+            qx._collect_statistics_batch(x)
+            quantize_input = 0
+        elif not qx.calibrated:
+            raise RuntimeError(
+                f"Quantizer not calibrated. Please run calibration first for {qx.quantizer_type} quantizer.")
+        elif qx.quantizer_type not in _lib.QTYPE_CODE:
+            raise ValueError(f"Unknown quantizer type: {qx.quantizer_type}. Supported types: 'minmax', 'log'")
+        use_lora = (not self.calibration_mode) and lora.enabled and lora.scaling != 0
+        prep = self._operands(key, qx, qw, lora, use_lora, quantize_input)
+
+        x2 = x.detach().contiguous().view(-1, self.in_features)
+        M, K, N = x2.shape[0], self.in_features, self.out_features
+        # a 3-D keep-dim input scale lifts a 2-D input to 3-D, as x / scale does in the reference
+        lead = tuple(x.shape[:-1])
+        if quantize_input and qx.scale.dim() > x.dim():
+            lead = (1,) * (qx.scale.dim() - x.dim()) + lead
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        if M == 0:
+            return y.view(*lead, N)
+        r = prep.r if use_lora else 0
+        lib = _lib.load()
+        ws = _lib.workspace(x.device, lib.spq_fwd_workspace_bytes(M, K, N, r, prep.path))
+        sx = qx.scale if quantize_input else None
+        zx = qx.zero_point if quantize_input else None
+        if quantize_input and (sx.device != x.device or sx.numel() not in (1, K)):
+            raise RuntimeError(f"input scale of shape {tuple(sx.shape)} on {sx.device} does not fit input {tuple(x.shape)}")
+        bias = self.linear.bias
+        a = _lib.FwdArgs(
+            M=M, K=K, N=N, r=r, bits=int(qx.num_bits), qtype=_lib.QTYPE_CODE.get(qx.quantizer_type, 0),
+            symmetric=1 if qx.symmetric else 0, quantize_input=quantize_input,
+            x_per_channel=1 if (quantize_input and sx.numel() > 1) else 0, path=prep.path,
+            x=x2.data_ptr(), sx=_lib.ptr(sx), zx=_lib.ptr(zx), w_prep=prep.w.data_ptr(),
+            w_rowscale=_lib.ptr(prep.w_rowscale), bias=_lib.ptr(bias), a_prep=_lib.ptr(prep.a) if r else None,
+            b_prep=_lib.ptr(prep.b) if r else None, lora_scaling=float(lora.scaling) if r else 0.0,
+            y=y.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel())
+        with torch.cuda.device(x.device):
+            rc = lib.spq_linear_lora_fwd(ctypes.byref(a), _lib.stream_ptr(x.device))
+        _lib.check(rc, "spq_linear_lora_fwd")
+        return y.view(*lead, N)
+
+    # ---- weight-side operands --------------------------------------------------------------------------------
+    def _choose_path(self, qx, qw, lora, quantize_input):
+        if self.operand_path != _lib.PATH_AUTO:
+            return self.operand_path
+        return _lib.PATH_F32
+
+    def _operands(self, key, qx, qw, lora, use_lora, quantize_input):
+        """FQ(W) [N,K], FQ(A)^T [r,K], FQ(B)^T [N,r] for the active bit-width.
+
+        The reference re-quantises these on every forward.  Here they are rebuilt on every call in training mode
+        and, in eval mode, only when their inputs changed: tensor identity + autograd version of W/A/B and the
+        calibration epoch of the quantizers.  (A write through ``weight.data`` does not bump the version; call
+        ``invalidate_operand_cache()`` after one in eval mode.)
+        """
+        if not qw.calibrated:
+            raise RuntimeError(
+                f"Quantizer not calibrated. Please run calibration first for {qw.quantizer_type} quantizer.")
+        W = self.linear.weight
+        path = self._choose_path(qx, qw, lora, quantize_input)
+        sig = [path, _sig(W), qw._epoch, _sig(qw.scale), _sig(qw.zero_point)]
+        if use_lora:
+            for q, t in ((lora.quantize_A, lora.lora_A), (lora.quantize_B, lora.lora_B)):
+                if not q.calibrated:
+                    raise RuntimeError(
+                        f"Quantizer not calibrated. Please run calibration first for {q.quantizer_type} quantizer.")
+                sig += [_sig(t), q._epoch, _sig(q.scale), _sig(q.zero_point)]
+        sig = tuple(sig)
+        prep = self._prepared.get(key)
+        if prep is not None and prep.sig == sig and self.cache_operands and not self.training:
+            return prep
+        prep = prep or _Prepared()
+        prep.path, prep.w_rowscale = path, None
+        with torch.no_grad():
+            prep.w = qw(W.detach())                                            # spq_fakequant -> [N,K]
+            if use_lora:
+                prep.a = _fq_transposed(lora.quantize_A, lora.lora_A.detach())  # [r,K]
+                prep.b = _fq_transposed(lora.quantize_B, lora.lora_B.detach())  # [N,r]
+                prep.r = lora.rank
+            else:
+                prep.a = prep.b = None
+                prep.r = 0
+        prep.sig = sig
+        self._prepared[key] = prep
+        return prep
+
+
+def _fq_transposed(q: LearnableFakeQuantize, t: torch.Tensor) -> torch.Tensor:
+    """FQ(t)^T for a 2-D LoRA factor whose scale is per column ([1, cols]) or per tensor."""
+    _lib.require_gpu(t, "LoRA factor")
+    rows, cols = t.shape
+    if q.num_bits >= 32:
+        return t.t().contiguous()
+    per_channel = 1 if q.scale.numel() > 1 else 0
+    if per_channel and q.scale.numel() != cols:
+        raise RuntimeError(f"LoRA scale of shape {tuple(q.scale.shape)} does not fit factor {tuple(t.shape)}")
+    out = torch.empty(cols, rows, dtype=torch.float32, device=t.device)
+    tc = t.contiguous()
+    with torch.cuda.device(t.device):
+        rc = _lib.load().spq_fakequant_transposed(
+            tc.data_ptr(), rows, cols, q.scale.data_ptr(), q.zero_point.data_ptr(), per_channel, int(q.num_bits),
+            _lib.QTYPE_CODE[q.quantizer_type], 1 if q.symmetric else 0, 1.0, out.data_ptr(),
+            _lib.stream_ptr(t.device))
+    _lib.check(rc, "spq_fakequant_transposed")
+    return out
