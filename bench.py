@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: SPLinearWithLoRA.forward on GPT-2-small c_fc (768 -> 3072), 4-bit minmax
+per-channel, LoRA rank 64, batch 8 x seq 1024 tokens per GPU (BASELINE.json metric; SURVEY.md §8d headline).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A step = one forward of the layer over one batch of synthetic activations already resident in HBM, including the
+per-call weight-side fake-quant that the reference also performs on every call (unless --hoist-weights).  Ranks are
+data-parallel replicas over the batch (weak scaling); the only collective is the all-reduce of the calibration
+min/max statistics, done once before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M_TOKENS, K_IN, N_OUT, RANK, BITS, BATCH = 8192, 768, 3072, 64, 4, 8
+FLOP_PER_STEP = 2 * M_TOKENS * K_IN * N_OUT + 2 * M_TOKENS * K_IN * RANK + 2 * M_TOKENS * RANK * N_OUT   # 42 681 237 504
+BYTES_PER_STEP = 4 * (M_TOKENS * K_IN + N_OUT * K_IN + K_IN * RANK + RANK * N_OUT + N_OUT + M_TOKENS * N_OUT) \
+    + 4 * (K_IN + N_OUT + RANK + N_OUT)                                                                        # ~136.29 MB
+PEAK = {"f32": 157.3, "f16": 2500.0, "hbm_gbs": 8000.0}   # MI355X_MICROARCH.md: dense MFMA TFLOP/s, HBM GB/s
+
+
+class HipEvents:
+    """Raw hipEvent pairs (the C ABI records them around the dominant kernel on the launch stream)."""
+
+    def __init__(self, n):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+        self.pairs = []
+        for _ in range(n):
+            b, e = ctypes.c_void_p(), ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(b)) == 0 and self.hip.hipEventCreate(ctypes.byref(e)) == 0
+            self.pairs.append((b, e))
+
+    def elapsed_ms(self):
+        out = []
+        for b, e in self.pairs:
+            ms = ctypes.c_float()
+            if self.hip.hipEventElapsedTime(ctypes.byref(ms), b, e) == 0:
+                out.append(ms.value)
+        return out
+
+    def destroy(self):
+        for b, e in self.pairs:
+            self.hip.hipEventDestroy(b); self.hip.hipEventDestroy(e)
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle (torch CPU ops in the reference's op order) on this host's cores, same workload."""
+    from oracle import ref_cpu as O
+    W, bias, A, B, x0, x1 = O.make_workload(M_TOKENS, K_IN, N_OUT, RANK, seed=0, batch=BATCH)
+    layer = O.build_calibrated_layer(W, bias, A, B, [x0, x1], BITS, "minmax", True, 64, RANK)
+    with torch.no_grad():
+        for _ in range(2):
+            layer.forward(x0)
+        times, t_end = [], time.perf_counter() + budget_s
+        while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 60):
+            t0 = time.perf_counter(); layer.forward(x0); times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    model = ""
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": round(FLOP_PER_STEP / med / 1e9, 2), "unit": "GFLOP/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{len(times)} full forwards of the same workload (M={M_TOKENS}), median "
+            f"{med * 1e3:.1f} ms, min {times[0] * 1e3:.1f} ms; host cpu_count={os.cpu_count()} [{model}]"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--path", choices=["auto", "f32", "f16x2"], default="auto")
+    ap.add_argument("--hoist-weights", action="store_true",
+                    help="reuse prepared weight operands across steps (eval-mode behaviour of the module)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import llm_qat_on_gpt2_amd as pkg
+    from oracle import ref_cpu as O   # workload generator only (shared with the CPU leg); never on the timed path
+
+    W, bias, A, B, _, _ = O.make_workload(8, K_IN, N_OUT, RANK, seed=0)          # replicated weights
+    gen = torch.Generator().manual_seed(1000 + 17 * rank)                        # this rank's batch shard
+
+    def act():
+        x = torch.randn(M_TOKENS, K_IN, generator=gen)
+        x = torch.where(torch.rand(M_TOKENS, K_IN, generator=gen) < 1e-3, x * 20, x)
+        return x.view(BATCH, M_TOKENS // BATCH, K_IN).to(dev)
+
+    layer = pkg.SPLinearWithLoRA(K_IN, N_OUT, [BITS, 32], {BITS: RANK, 32: 0}, {BITS: 64, 32: 0},
+                                 {BITS: "minmax", 32: None}, per_channel=True)
+    key = f"{BITS}bit"
+    with torch.no_grad():
+        layer.linear.weight.copy_(W); layer.linear.bias.copy_(bias)
+        layer.lora_adapters[key].lora_A.copy_(A); layer.lora_adapters[key].lora_B.copy_(B)
+    layer = layer.to(dev).eval()
+    layer.set_precision(BITS)
+    layer.operand_path = {"auto": pkg._lib.PATH_AUTO, "f32": pkg._lib.PATH_F32, "f16x2": pkg._lib.PATH_F16X2}[args.path]
+    layer.cache_operands = bool(args.hoist_weights)
+
+    # calibration: 2 local batches per rank, then ONE all-reduce(MAX) of [-min | max] (RCCL) -> identical scales
+    t0 = time.perf_counter()
+    exchanged = pkg.calibrate_layer(layer, BITS, [act(), act()])
+    torch.cuda.synchronize()
+    calib_ms = (time.perf_counter() - t0) * 1e3
+
+    x = act()
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = layer(x)
+        ev = HipEvents(args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            layer._gemm_events = ev.pairs[i]
+            y = layer(x)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        layer._gemm_events = None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    gemm_ms = ev.elapsed_ms()
+    ev.destroy()
+    path_used = layer._prepared[key].path
+    assert bool(torch.isfinite(y).all())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * FLOP_PER_STEP * args.steps / elapsed / 1e9
+        gemm_avg_ms = sum(gemm_ms) / max(1, len(gemm_ms))
+        is_f16 = path_used == pkg._lib.PATH_F16X2
+        achieved = FLOP_PER_STEP / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms > 0 else 0.0
+        peak = PEAK["f16"] if is_f16 else PEAK["f32"]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("f16x2" if is_f16 else "f32", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "fused quant-GEMM-LoRA fwd GFLOP/s per GPU, GPT-2 c_fc 768→3072 @ 4-bit",
+            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16x2-limb operands, f32 accumulate (fp32-accurate)" if is_f16 else "f32",
+            "data": "synthetic",
+            "config": {"workload": "SPLinearWithLoRA c_fc 768->3072, 4-bit minmax per-channel + LoRA r=64, "
+                                   "batch 8 x seq 1024 = 8192 tokens per GPU (SURVEY.md 8d headline)",
+                       "tokens_per_gpu": M_TOKENS, "parallelism": f"dp{world} (replicas over the batch)",
+                       "operand_path": "f16x2" if is_f16 else "f32", "weights_requantized_every_step": not args.hoist_weights,
+                       "flop_per_step_per_gpu": FLOP_PER_STEP, "algorithmic_bytes_per_step_per_gpu": BYTES_PER_STEP},
+            "value_per_gpu": round(value / world, 1),
+            "algorithmic_GBps_per_gpu": round(BYTES_PER_STEP * args.steps / elapsed / 1e9, 1),
+            "frac_of_hbm_peak": round(BYTES_PER_STEP * args.steps / elapsed / 1e9 / PEAK["hbm_gbs"], 4),
+            "calibration": {"ms": round(calib_ms, 2), "allreduce_elements": exchanged},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16x2 (dense contraction + LoRA-up + bias)" if is_f16
+                         else "gemm_f32_nt (dense contraction + LoRA-up + bias)",
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "peak_dtype": "f16 dense MFMA (2 limb products per algorithmic product)" if is_f16
+                         else "f32-input MFMA", "kernel_ms_avg": round(gemm_avg_ms, 4),
+                         "frac_vs_f32_mfma_peak": round(achieved / PEAK["f32"], 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

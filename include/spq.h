@@ -127,12 +127,16 @@ typedef struct spq_fwd_args {
   const float* w_rowscale;     /* F16X2: per-row power-of-two descale [N]; else NULL */
   const float* bias;           /* [N] or NULL */
   const float* a_prep;         /* fp32 FQ(A)^T [r, K] */
-  const void* b_prep;          /* F32: fp32 scaling*FQ(B)^T [N, r]; F16X2: limb planes */
-  float lora_scaling;          /* alpha / rank, applied where b_prep does not already carry it */
+  const void* b_prep;          /* F32: fp32 FQ(B)^T [N, r]; F16X2: limb planes */
+  float lora_scaling;          /* alpha / rank: multiplies the low-rank partial sum (lora.py:53) */
   /* output + scratch */
   float* y;                    /* [M, N] */
   void* workspace;
   size_t workspace_bytes;
+  /* profiling hooks (nullable hipEvent_t): recorded on `stream` right before / after the dominant
+   * (dense-contraction) kernel, so a benchmark can time that kernel inside its own timed region */
+  void* ev_gemm_begin;
+  void* ev_gemm_end;
 } spq_fwd_args;
 
 size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path);

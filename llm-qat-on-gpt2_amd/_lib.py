@@ -31,7 +31,8 @@ class FwdArgs(C.Structure):
                 ("x", _p), ("sx", _p), ("zx", _p),
                 ("w_prep", _p), ("w_rowscale", _p), ("bias", _p), ("a_prep", _p), ("b_prep", _p),
                 ("lora_scaling", _f),
-                ("y", _p), ("workspace", _p), ("workspace_bytes", _sz)]
+                ("y", _p), ("workspace", _p), ("workspace_bytes", _sz),
+                ("ev_gemm_begin", _p), ("ev_gemm_end", _p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/spq.h declares (tests/test_cabi.py checks).

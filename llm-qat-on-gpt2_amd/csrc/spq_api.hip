@@ -102,7 +102,10 @@ extern "C" int spq_linear_lora_fwd(const spq_fwd_args* a, spq_stream_t stream) {
     if (rc) return rc;
     act = xq;
   }
-  return launch_gemm_f32_nt(act, a->K, (const float*)a->w_prep, a->K, a->K, a->r > 0 ? t : nullptr, a->r,
-                            (const float*)a->b_prep, a->r, a->r, a->lora_scaling, a->bias, a->y, a->N, a->M, a->N,
-                            st);
+  if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
+  rc = launch_gemm_f32_nt(act, a->K, (const float*)a->w_prep, a->K, a->K, a->r > 0 ? t : nullptr, a->r,
+                          (const float*)a->b_prep, a->r, a->r, a->lora_scaling, a->bias, a->y, a->N, a->M, a->N,
+                          st);
+  if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
+  return rc;
 }

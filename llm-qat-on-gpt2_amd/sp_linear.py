@@ -121,6 +121,7 @@ class SPLinearWithLoRA(nn.Module):
         self.operand_path = _lib.PATH_AUTO        # enum spq_path; AUTO picks the fastest valid one
         self.cache_operands = True                # reuse prepared operands in eval mode (see _operands)
         self._prepared = {}
+        self._gemm_events = None                  # (hipEvent_t, hipEvent_t) around the dominant kernel, for bench.py
 
     # ---- precision switching (lora.py:105-125): attribute flips only ---------------------------------------
     def set_precision(self, bits) -> int:
@@ -216,7 +217,9 @@ class SPLinearWithLoRA(nn.Module):
             x=x2.data_ptr(), sx=_lib.ptr(sx), zx=_lib.ptr(zx), w_prep=prep.w.data_ptr(),
             w_rowscale=_lib.ptr(prep.w_rowscale), bias=_lib.ptr(bias), a_prep=_lib.ptr(prep.a) if r else None,
             b_prep=_lib.ptr(prep.b) if r else None, lora_scaling=float(lora.scaling) if r else 0.0,
-            y=y.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel())
+            y=y.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
+            ev_gemm_begin=self._gemm_events[0] if self._gemm_events else None,
+            ev_gemm_end=self._gemm_events[1] if self._gemm_events else None)
         with torch.cuda.device(x.device):
             rc = lib.spq_linear_lora_fwd(ctypes.byref(a), _lib.stream_ptr(x.device))
         _lib.check(rc, "spq_linear_lora_fwd")
