@@ -155,7 +155,7 @@ def main():
     elapsed = float(t.item())
     gemm_ms = ev.elapsed_ms()
     ev.destroy()
-    path_used = layer._prepared[key].path
+    path_used = layer._last_path
     assert bool(torch.isfinite(y).all())
 
     if rank == 0:

@@ -1,9 +1,595 @@
-// placeholder until the 2-limb fp16 path lands
+// SPQ_PATH_F16X2: the dense contraction on f16 matrix cores at fp32 accuracy.
+//
+// For a symmetric minmax input quantizer the fake-quantised activation is  FQ(x)[m,k] = q[m,k] * sx[k]  with q an
+// INTEGER level (|q| <= 2^(b-1)-1).  The per-channel scale sx[k] lives on the contraction axis, so it is folded into
+// the weight operand once per (weights, scales):
+//        y[m,n] = sum_k q[m,k] * W'[n,k],      W'[n,k] = FQ(W)[n,k] * sx[k]      (exact product, formed in fp64)
+// q is exact in fp16 for b <= 12; W' is split into two fp16 limbs  W' * 2^e[n] = hi + lo  (22 significant bits,
+// |err| <= 2^-22 |W'|, the per-row power of two e[n] keeps the limbs in fp16's normal range), so
+//        y[m,n] = 2^-e[n] * sum_k ( q*hi + q*lo )                                 two f16 MFMAs per k-block,
+// every product exact, accumulated in fp32 by the MFMA.  The LoRA branch consumes the RAW fp32 x (lora.py:149):
+//        t = x . FQ(A)   on fp32-input MFMA in the activation pass (below),  t * 2^g[m] = thi + tlo,
+//        u[m,n] = 2^-g[m] 2^-e[n] * sum_j ( thi*Bhi + thi*Blo + tlo*Bhi ),   B' = scaling * FQ(B)^T * 2^e[n] = Bhi + Blo.
+//
+// Kernels
+//   prep_f16x2_kernel : per output row n: FQ(W) row, fold sx, FQ(B) column, common exponent, limb split   (HBM scan)
+//   xpass_kernel      : one read of x: integer levels -> fp16 [M,K]; t = x.FQ(A) (f32 MFMA) -> 2 limbs + row scale
+//   gemm_f16x2_kernel : 256x128 tile, 8 waves (4x2, 64x64 each), BK=64, direct global->LDS (16 B), XOR-swizzled,
+//                       double-buffered; v_mfma_f32_32x32x16_f16; epilogue scale + bias, full-line stores
+#include <hip/hip_fp16.h>
+
 #include "spq_common.h"
+
 namespace spq {
-size_t fwd_f16x2_workspace_bytes(int64_t, int64_t, int64_t, int64_t) { return 0; }
-int fwd_f16x2(const spq_fwd_args*, hipStream_t) {
-  set_error("spq_linear_lora_fwd: SPQ_PATH_F16X2 not built");
-  return SPQ_ERR_UNSUPPORTED;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int64_t pad_to(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+constexpr int GM = 256, GN = 128, GK = 64;     // GEMM block tile
+constexpr int XR = 32, XK = 64;                // activation-pass tile: rows per block, k per chunk
+
+struct F16x2Layout {                            // workspace carve-up, all offsets 256-B aligned
+  int64_t Mp, Kp, Rp;
+  size_t off_qx, off_thi, off_tlo, off_rowinv, total;
+};
+
+static F16x2Layout make_layout(int64_t M, int64_t K, int64_t r) {
+  F16x2Layout L;
+  L.Mp = pad_to(M, GM); L.Kp = pad_to(K, GK); L.Rp = r > 0 ? pad_to(r, GK) : 0;
+  size_t o = 0;
+  L.off_qx = o; o += pad_to((size_t)L.Mp * L.Kp * 2, 256);
+  L.off_thi = o; o += pad_to((size_t)L.Mp * L.Rp * 2, 256);
+  L.off_tlo = o; o += pad_to((size_t)L.Mp * L.Rp * 2, 256);
+  L.off_rowinv = o; o += pad_to((size_t)L.Mp * 4, 256);
+  L.total = o + 256;
+  return L;
 }
+
+size_t fwd_f16x2_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r) { return make_layout(M, K, r).total; }
+
+// power of two p with  v_max * p  in [2^13, 2^14)   (p = 1 for v_max == 0 or non-finite)
+__device__ __forceinline__ float pow2_scale_for(float vmax) {
+  if (!(vmax > 0.f) || !(vmax < INFINITY)) return 1.f;
+  int ex;
+  (void)frexpf(vmax, &ex);            // vmax = f * 2^ex, f in [0.5, 1)
+  return ldexpf(1.f, 14 - ex);
+}
+
+// =================================================================================================
+// Weight-side operand preparation.  One workgroup per output row n (grid = Np rows; rows >= N are zero).
+//   Whi/Wlo [Np, Kp]  <- FQ(W)[n,:] * sx[:]  * 2^e[n]
+//   Bhi/Blo [Np, Rp]  <- scaling * FQ(B)[:, n] * 2^e[n]
+//   rowscale[n] = 2^-e[n]
+// =================================================================================================
+struct PrepArgs {
+  const float* W; const float* sw; const float* zw;   // [N,K], weight quantizer params ([N] or [1])
+  const float* B; const float* sb; const float* zb;   // [r,N], LoRA-B quantizer params ([N] or [1]); B may be null
+  const float* sx;                                    // input scale [K] or [1]
+  _Float16 *Whi, *Wlo, *Bhi, *Blo;
+  float* rowscale;
+  int N, K, r, Kp, Rp;
+  int w_pc, w_bits, w_qtype, w_sym;
+  int b_pc, b_bits, b_qtype, b_sym;
+  int x_pc;
+  float scaling;
+};
+
+template <int QT, bool SYM>
+__device__ __forceinline__ float fq_value(float v, float s, float z, int bits) {
+  if (QT == SPQ_MINMAX) {
+    float qlo, qhi;
+    if (SYM) { qhi = (float)((1 << (bits - 1)) - 1); qlo = -qhi; }
+    else { qlo = 0.f; qhi = (float)((1u << bits) - 1u); }
+    return minmax_dequant<SYM>(minmax_level<SYM>(v, s, z, qlo, qhi), s, z);
+  } else {
+    const LogParams lp = make_log_params(bits, SYM);
+    return log_dequant<SYM>(v, log_level<SYM>(v, z, s, lp), z, s, lp);
+  }
+}
+
+__device__ __forceinline__ float fq_dispatch(float v, float s, float z, int bits, int qtype, int sym) {
+  if (bits >= 32) return v;
+  if (qtype == SPQ_MINMAX) return sym ? fq_value<SPQ_MINMAX, true>(v, s, z, bits) : fq_value<SPQ_MINMAX, false>(v, s, z, bits);
+  return sym ? fq_value<SPQ_LOG, true>(v, s, z, bits) : fq_value<SPQ_LOG, false>(v, s, z, bits);
+}
+
+__device__ __forceinline__ void split2(double v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;                     // round-to-nearest fp16
+  lo = (_Float16)(v - (double)hi);      // exact residual in fp64, rounded once
+}
+
+__global__ __launch_bounds__(256) void prep_f16x2_kernel(PrepArgs a) {
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  __shared__ float s_red[4];
+  __shared__ float s_scale;
+  _Float16* whi = a.Whi + (int64_t)n * a.Kp;
+  _Float16* wlo = a.Wlo + (int64_t)n * a.Kp;
+  _Float16* bhi = a.Bhi ? a.Bhi + (int64_t)n * a.Rp : nullptr;
+  _Float16* blo = a.Blo ? a.Blo + (int64_t)n * a.Rp : nullptr;
+  if (n >= a.N) {                       // padding rows: zeros
+    for (int k = tid; k < a.Kp; k += 256) { whi[k] = (_Float16)0.f; wlo[k] = (_Float16)0.f; }
+    if (bhi) for (int j = tid; j < a.Rp; j += 256) { bhi[j] = (_Float16)0.f; blo[j] = (_Float16)0.f; }
+    if (tid == 0) a.rowscale[n] = 1.f;
+    return;
+  }
+  const float swn = a.sw[a.w_pc ? n : 0], zwn = a.zw[a.w_pc ? n : 0];
+  // pass 1: row maximum of |W'| and |B'|
+  float vmax = 0.f;
+  for (int k = tid; k < a.K; k += 256) {
+    const float wq = fq_dispatch(a.W[(int64_t)n * a.K + k], swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
+    const double wp = (double)wq * (double)a.sx[a.x_pc ? k : 0];
+    vmax = fmaxf(vmax, fabsf((float)wp));
+  }
+  if (a.B) {
+    const float sbn = a.sb[a.b_pc ? n : 0], zbn = a.zb[a.b_pc ? n : 0];
+    for (int j = tid; j < a.r; j += 256) {
+      const float bq = fq_dispatch(a.B[(int64_t)j * a.N + n], sbn, zbn, a.b_bits, a.b_qtype, a.b_sym);
+      vmax = fmaxf(vmax, fabsf(bq * a.scaling));
+    }
+  }
+  vmax = wave_max(vmax);
+  if ((tid & 63) == 0) s_red[tid >> 6] = vmax;
+  __syncthreads();
+  if (tid == 0) {
+    const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    const float p = pow2_scale_for(m * 1.0000002f);   // margin: the fp32 max may sit 1 ulp under the fp64 product
+    s_scale = p;
+    a.rowscale[n] = 1.0f / p;                          // exact: p is a power of two
+  }
+  __syncthreads();
+  const double p = (double)s_scale;
+  // pass 2: limbs (recomputed rather than staged: the row is tiny and L2-resident)
+  for (int k = tid; k < a.Kp; k += 256) {
+    _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
+    if (k < a.K) {
+      const float wq = fq_dispatch(a.W[(int64_t)n * a.K + k], swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
+      split2((double)wq * (double)a.sx[a.x_pc ? k : 0] * p, h, l);
+    }
+    whi[k] = h; wlo[k] = l;
+  }
+  if (bhi) {
+    const float sbn = a.B ? a.sb[a.b_pc ? n : 0] : 1.f, zbn = a.B ? a.zb[a.b_pc ? n : 0] : 0.f;
+    for (int j = tid; j < a.Rp; j += 256) {
+      _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
+      if (a.B && j < a.r) {
+        const float bq = fq_dispatch(a.B[(int64_t)j * a.N + n], sbn, zbn, a.b_bits, a.b_qtype, a.b_sym);
+        split2((double)(bq * a.scaling) * p, h, l);    // (t@Bq)*scaling == t@(Bq*scaling) up to one fp32 rounding
+      }
+      bhi[j] = h; blo[j] = l;
+    }
+  }
+}
+
+// =================================================================================================
+// Activation pass.  Block = 256 threads, 32 rows of x.
+//   qx[m, k]  = (fp16) clamp(rint(x/sx), -n, n)                          (quantization_methods.py:14-15)
+//   t[m, j]   = sum_k x[m,k] * FQ(A)[k,j]      fp32-input MFMA, K split over the 4 waves, summed in LDS
+//   thi/tlo   = two fp16 limbs of t * 2^g[m];  rowinv[m] = 2^-g[m]
+// =================================================================================================
+struct XPassArgs {
+  const float* x; const float* sx; const float* zx; const float* aT;   // x [M,K]; aT = FQ(A)^T [r,K] fp32
+  _Float16 *qx, *thi, *tlo; float* rowinv;
+  int M, K, r, Kp, Rp;
+  int x_pc, bits;
+};
+
+constexpr int XLD = XK + 4;   // fp32 LDS row stride 272 B: slot = 17*row + c (mod 16) -> conflict-free b128 reads
+
+template <int RT>  // RT = Rp / 32 column tiles of t (2 for r<=64, 4 for r<=128)
+__global__ __launch_bounds__(256) void xpass_kernel(XPassArgs a) {
+  constexpr int RP = RT * 32;
+  constexpr int SM_X = XR * XLD, SM_A = RP * XLD;
+  constexpr int SM_RED = 4 * XR * RP;
+  __shared__ __attribute__((aligned(16))) float smem[(SM_X + SM_A) > SM_RED ? (SM_X + SM_A) : SM_RED];
+  float* xs = smem;
+  float* as = smem + SM_X;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int m0 = blockIdx.x * XR;
+  const float qhi = (float)((1 << (a.bits - 1)) - 1), qlo = -qhi;
+  const bool with_lora = a.r > 0;
+
+  f32x16 acc[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  float4 rx[2];
+  float4 ra[RT * 2];
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                 // x: 32 rows x 16 float4
+      const int idx = tid + 256 * i, row = idx >> 4, c = (idx & 15) << 2;
+      const int m = m0 + row, k = k0 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < a.M) {
+        const float* p = a.x + (int64_t)m * a.K + k;
+        if (k + 3 < a.K && ((a.K & 3) == 0)) v = *reinterpret_cast<const float4*>(p);
+        else {
+          if (k + 0 < a.K) v.x = p[0];
+          if (k + 1 < a.K) v.y = p[1];
+          if (k + 2 < a.K) v.z = p[2];
+          if (k + 3 < a.K) v.w = p[3];
+        }
+      }
+      rx[i] = v;
+    }
+    if (with_lora) {
+#pragma unroll
+      for (int i = 0; i < RT * 2; ++i) {          // FQ(A)^T: RP rows x 16 float4
+        const int idx = tid + 256 * i, row = idx >> 4, c = (idx & 15) << 2;
+        const int k = k0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < a.r) {
+          const float* p = a.aT + (int64_t)row * a.K + k;
+          if (k + 3 < a.K && ((a.K & 3) == 0)) v = *reinterpret_cast<const float4*>(p);
+          else {
+            if (k + 0 < a.K) v.x = p[0];
+            if (k + 1 < a.K) v.y = p[1];
+            if (k + 2 < a.K) v.z = p[2];
+            if (k + 3 < a.K) v.w = p[3];
+          }
+        }
+        ra[i] = v;
+      }
+    }
+  };
+
+  load_chunk(0);
+  for (int k0 = 0; k0 < a.Kp; k0 += XK) {
+    __syncthreads();
+    // quantise + stage this chunk
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 4, c = (idx & 15) << 2;
+      const int m = m0 + row, k = k0 + c;
+      const float4 v = rx[i];
+      *reinterpret_cast<float4*>(xs + row * XLD + c) = v;
+      float s0, s1, s2, s3;
+      if (a.x_pc) {
+        s0 = (k + 0 < a.K) ? a.sx[k + 0] : 1.f; s1 = (k + 1 < a.K) ? a.sx[k + 1] : 1.f;
+        s2 = (k + 2 < a.K) ? a.sx[k + 2] : 1.f; s3 = (k + 3 < a.K) ? a.sx[k + 3] : 1.f;
+      } else { s0 = s1 = s2 = s3 = a.sx[0]; }
+      union { _Float16 h[4]; uint2 u; } q;
+      q.h[0] = (_Float16)minmax_level<true>(v.x, s0, 0.f, qlo, qhi);
+      q.h[1] = (_Float16)minmax_level<true>(v.y, s1, 0.f, qlo, qhi);
+      q.h[2] = (_Float16)minmax_level<true>(v.z, s2, 0.f, qlo, qhi);
+      q.h[3] = (_Float16)minmax_level<true>(v.w, s3, 0.f, qlo, qhi);
+      if (m < a.M) *reinterpret_cast<uint2*>(a.qx + (int64_t)m * a.Kp + k) = q.u;   // k < Kp always; pad k -> level 0
+    }
+    if (with_lora) {
+#pragma unroll
+      for (int i = 0; i < RT * 2; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 4, c = (idx & 15) << 2;
+        *reinterpret_cast<float4*>(as + row * XLD + c) = ra[i];
+      }
+    }
+    __syncthreads();
+    if (k0 + XK < a.Kp) load_chunk(k0 + XK);
+    if (with_lora) {
+      // wave w owns k in [16w, 16w+16) of the chunk; lane half h owns 8 contiguous k of those
+      const int l31 = lane & 31, h = lane >> 5;
+      const float* pa = xs + l31 * XLD + 16 * w + 8 * h;
+      float av[8];
+      *reinterpret_cast<float4*>(av) = *reinterpret_cast<const float4*>(pa);
+      *reinterpret_cast<float4*>(av + 4) = *reinterpret_cast<const float4*>(pa + 4);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const float* pb = as + (t * 32 + l31) * XLD + 16 * w + 8 * h;
+        float bv[8];
+        *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(pb);
+        *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(pb + 4);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (!with_lora) return;
+  // reduce the 4 per-wave partial sums: red[w][row][col]
+  __syncthreads();
+  float* red = smem;
+  {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        red[(w * XR + row) * RP + t * 32 + l31] = acc[t][e];
+      }
+  }
+  __syncthreads();
+  // thread -> (row = tid>>3, 8-column segment(s)); 8 consecutive lanes share a row
+  const int row = tid >> 3, seg = tid & 7;
+  constexpr int NSEG = RP / 64;            // 8-col segments per thread
+  float tv[NSEG][8];
+  float rmax = 0.f;
+#pragma unroll
+  for (int sgi = 0; sgi < NSEG; ++sgi) {
+    const int c0 = (sgi * 8 + seg) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float p0 = red[(0 * XR + row) * RP + c0 + j], p1 = red[(1 * XR + row) * RP + c0 + j];
+      const float p2 = red[(2 * XR + row) * RP + c0 + j], p3 = red[(3 * XR + row) * RP + c0 + j];
+      const float v = (p0 + p1) + (p2 + p3);
+      tv[sgi][j] = v;
+      rmax = fmaxf(rmax, fabsf(v));
+    }
+  }
+  rmax = fmaxf(rmax, __shfl_xor(rmax, 1, 64));
+  rmax = fmaxf(rmax, __shfl_xor(rmax, 2, 64));
+  rmax = fmaxf(rmax, __shfl_xor(rmax, 4, 64));
+  const float p = pow2_scale_for(rmax);
+  const int m = m0 + row;
+  if (m < a.M) {
+    if (seg == 0) a.rowinv[m] = 1.0f / p;
+#pragma unroll
+    for (int sgi = 0; sgi < NSEG; ++sgi) {
+      const int c0 = (sgi * 8 + seg) * 8;
+      union { _Float16 h[8]; uint4 u; } hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float ts = tv[sgi][j] * p;                 // exact (power of two)
+        hi.h[j] = (_Float16)ts;
+        lo.h[j] = (_Float16)(ts - (float)hi.h[j]);       // exact residual, rounded once
+      }
+      *reinterpret_cast<uint4*>(a.thi + (int64_t)m * a.Rp + c0) = hi.u;
+      *reinterpret_cast<uint4*>(a.tlo + (int64_t)m * a.Rp + c0) = lo.u;
+    }
+  }
+}
+
+// =================================================================================================
+// The contraction.
+// =================================================================================================
+struct GemmF16Args {
+  const _Float16 *qx, *thi, *tlo;           // [Mp,Kp], [Mp,Rp], [Mp,Rp]
+  const _Float16 *Whi, *Wlo, *Bhi, *Blo;    // [Np,Kp] x2, [Np,Rp] x2
+  const float *rowinv, *rowscale, *bias;    // [Mp], [Np], [N] (nullable)
+  float* y;
+  int M, N, Kp, Rp;                         // Rp = 0: no LoRA
+  int tiles_m, tiles_n;
+};
+
+constexpr int STAGE_A = GM * GK * 2;               // 32 KB
+constexpr int STAGE_B = GN * GK * 2;               // 16 KB per limb
+constexpr int STAGE_BYTES = STAGE_A + 2 * STAGE_B; // 64 KB
+
+// LDS image of a [rows][64 f16] tile: 128-B rows of eight 16-B chunks; chunk c of row r is stored at chunk position
+// c ^ ((r>>1)&7).  With row = lane&31 per fragment read, the 16 lanes of every ds_read_b128 group then hit 16
+// distinct 16-B slots of the 256-B bank row (rows of equal parity differ in (r>>1)&7): conflict-free.
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(GemmF16Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+
+  // XCD-aware tile order (speed only): the workgroups of one XCD walk a contiguous run of tiles, N fastest.
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int bm = (wgid / g.tiles_n) * GM;
+  const int bn = (wgid % g.tiles_n) * GN;
+
+  const int nl = (g.Rp / GK) * 2;           // LoRA stages: per 64-wide block of r: (thi x {Bhi,Blo}), (tlo x {Bhi})
+  const int T = nl + g.Kp / GK;
+
+  // per-lane source coordinates of one 1-KB glds piece: 8 rows x 8 chunks
+  const int prow = lane >> 3, pchunk = lane & 7;
+
+  auto issue = [&](int t, int buf) {
+    char* sb = smem + buf * STAGE_BYTES;
+    const _Float16 *A, *Bh, *Bl;
+    int64_t lda, ldb; int k0; bool two;
+    if (t < nl) {
+      const int blk = t >> 1, which = t & 1;
+      A = which ? g.tlo : g.thi; lda = g.Rp; Bh = g.Bhi; Bl = g.Blo; ldb = g.Rp; k0 = blk * GK; two = (which == 0);
+    } else {
+      A = g.qx; lda = g.Kp; Bh = g.Whi; Bl = g.Wlo; ldb = g.Kp; k0 = (t - nl) * GK; two = true;
+    }
+    // A: 32 pieces of 8 rows; wave w issues pieces 4w..4w+3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = 4 * w + i;
+      const int row = piece * 8 + prow;
+      const _Float16* src = A + (int64_t)(bm + row) * lda + k0 + swz(row, pchunk) * 8;
+      glds16(src, sb + piece * 1024);
+    }
+    // B: 16 pieces per limb; wave w issues pieces 2w, 2w+1 of each limb
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = 2 * w + i;
+      const int row = piece * 8 + prow;
+      const int64_t off = (int64_t)(bn + row) * ldb + k0 + swz(row, pchunk) * 8;
+      glds16(Bh + off, sb + STAGE_A + piece * 1024);
+      if (two) glds16(Bl + off, sb + STAGE_A + STAGE_B + piece * 1024);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int l31 = lane & 31, h = lane >> 5;
+  auto compute = [&](int buf, bool two) {
+    const char* sa = smem + buf * STAGE_BYTES;
+    const char* sbh = sa + STAGE_A;
+    const char* sbl = sbh + STAGE_B;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {                       // four k16 blocks of the 64-deep stage
+      const int c = 2 * s + h;
+      f16x8 af[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ra = wm * 64 + t * 32 + l31;
+        af[t] = *reinterpret_cast<const f16x8*>(sa + ra * 128 + swz(ra, c) * 16);
+        const int rb = wn * 64 + t * 32 + l31;
+        bh[t] = *reinterpret_cast<const f16x8*>(sbh + rb * 128 + swz(rb, c) * 16);
+        if (two) bl[t] = *reinterpret_cast<const f16x8*>(sbl + rb * 128 + swz(rb, c) * 16);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          if (two) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  issue(0, 0);
+  __syncthreads();                                      // drains the LDS-DMA (vmcnt(0)) and joins the waves
+  for (int t = 0; t < T; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < T) issue(t + 1, buf ^ 1);               // next stage lands under this stage's MFMAs
+    if (t == nl && nl > 0) {                            // LoRA partial sums -> units of the base sum: * 2^-g[m]
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = bm + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float ri = g.rowinv[m];
+          acc[tm][0][e] *= ri; acc[tm][1][e] *= ri;
+        }
+    }
+    if (t < nl && (t & 1)) compute(buf, false); else compute(buf, true);
+    __syncthreads();
+  }
+
+  // epilogue: y = acc * 2^-e[n] + bias[n]; C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int n = bn + wn * 64 + tn * 32 + l31;
+    if (n >= g.N) continue;
+    const float rs = g.rowscale[n];
+    const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = bm + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < g.M) g.y[(int64_t)m * g.N + n] = acc[tm][tn][e] * rs + bv;
+      }
+  }
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+struct PrepLayout { int64_t Np, Kp, Rp; size_t off_whi, off_wlo, off_bhi, off_blo, total; };
+static PrepLayout make_prep_layout(int64_t N, int64_t K, int64_t r) {
+  PrepLayout L;
+  L.Np = pad_to(N, GN); L.Kp = pad_to(K, GK); L.Rp = r > 0 ? pad_to(r, GK) : 0;
+  size_t o = 0;
+  L.off_whi = o; o += pad_to((size_t)L.Np * L.Kp * 2, 256);
+  L.off_wlo = o; o += pad_to((size_t)L.Np * L.Kp * 2, 256);
+  L.off_bhi = o; o += pad_to((size_t)L.Np * L.Rp * 2, 256);
+  L.off_blo = o; o += pad_to((size_t)L.Np * L.Rp * 2, 256);
+  L.total = o + 256;
+  return L;
+}
+
+static bool f16x2_shape_ok(int64_t M, int64_t K, int64_t N, int64_t r) {
+  return r <= 128 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30);
+}
+
+int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
+  if (!(a->quantize_input && a->qtype == SPQ_MINMAX && a->symmetric && a->bits >= 2 && a->bits <= 12)) {
+    set_error("spq_linear_lora_fwd: SPQ_PATH_F16X2 needs a symmetric minmax input quantizer with 2..12 bits "
+              "(got qtype=%d symmetric=%d bits=%d quantize_input=%d)", a->qtype, a->symmetric, a->bits, a->quantize_input);
+    return SPQ_ERR_UNSUPPORTED;
+  }
+  if (!f16x2_shape_ok(a->M, a->K, a->N, a->r)) {
+    set_error("spq_linear_lora_fwd: SPQ_PATH_F16X2 supports LoRA rank <= 128 (got %lld)", (long long)a->r);
+    return SPQ_ERR_UNSUPPORTED;
+  }
+  SPQ_REQUIRE(a->w_rowscale, "spq_linear_lora_fwd: w_rowscale missing for SPQ_PATH_F16X2");
+  const F16x2Layout L = make_layout(a->M, a->K, a->r);
+  const PrepLayout P = make_prep_layout(a->N, a->K, a->r);
+  char* ws = (char*)a->workspace;
+  const char* wp = (const char*)a->w_prep;
+
+  XPassArgs x;
+  x.x = a->x; x.sx = a->sx; x.zx = a->zx; x.aT = a->a_prep;
+  x.qx = (_Float16*)(ws + L.off_qx); x.thi = (_Float16*)(ws + L.off_thi); x.tlo = (_Float16*)(ws + L.off_tlo);
+  x.rowinv = (float*)(ws + L.off_rowinv);
+  x.M = (int)a->M; x.K = (int)a->K; x.r = (int)a->r; x.Kp = (int)L.Kp; x.Rp = (int)L.Rp;
+  x.x_pc = a->x_per_channel; x.bits = a->bits;
+  const unsigned xgrid = (unsigned)((a->M + XR - 1) / XR);
+  if (L.Rp <= 64) xpass_kernel<2><<<xgrid, 256, 0, st>>>(x);
+  else xpass_kernel<4><<<xgrid, 256, 0, st>>>(x);
+  int rc = check_launch("spq_linear_lora_fwd(xpass)");
+  if (rc) return rc;
+
+  GemmF16Args g;
+  g.qx = x.qx; g.thi = x.thi; g.tlo = x.tlo;
+  g.Whi = (const _Float16*)(wp + P.off_whi); g.Wlo = (const _Float16*)(wp + P.off_wlo);
+  g.Bhi = (const _Float16*)(wp + P.off_bhi); g.Blo = (const _Float16*)(wp + P.off_blo);
+  g.rowinv = x.rowinv; g.rowscale = a->w_rowscale; g.bias = a->bias; g.y = a->y;
+  g.M = (int)a->M; g.N = (int)a->N; g.Kp = (int)L.Kp; g.Rp = (int)L.Rp;
+  g.tiles_m = (int)(L.Mp / GM); g.tiles_n = (int)(P.Np / GN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * STAGE_BYTES);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %d B): %s", 2 * STAGE_BYTES, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
+  gemm_f16x2_kernel<<<(unsigned)(g.tiles_m * g.tiles_n), 512, 2 * STAGE_BYTES, st>>>(g);
+  if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
+  return check_launch("spq_linear_lora_fwd(gemm_f16x2)");
+}
+
 }  // namespace spq
+
+using namespace spq;
+
+extern "C" size_t spq_prep_f16x2_bytes(int64_t N, int64_t K, int64_t r) {
+  if (N <= 0 || K <= 0 || r < 0) return 0;
+  return make_prep_layout(N, K, r).total;
+}
+
+extern "C" int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const float* sw, const float* zw,
+                                 int w_per_channel, int w_bits, int w_qtype, int w_symmetric, const float* B,
+                                 int64_t r, const float* sb, const float* zb, int b_per_channel, int b_bits,
+                                 int b_qtype, int b_symmetric, float scaling, const float* sx, int x_per_channel,
+                                 void* w_prep, size_t w_prep_bytes, float* w_rowscale, spq_stream_t stream) {
+  SPQ_REQUIRE(W && sw && zw && sx && w_prep && w_rowscale, "spq_prepare_f16x2: null pointer");
+  SPQ_REQUIRE(N > 0 && K > 0 && r >= 0, "spq_prepare_f16x2: bad shape");
+  SPQ_REQUIRE(r == 0 || (B && sb && zb), "spq_prepare_f16x2: LoRA-B operands missing");
+  SPQ_REQUIRE(w_bits >= 1 && b_bits >= 0, "spq_prepare_f16x2: bad bit-width");
+  if (!f16x2_shape_ok(1, K, N, r)) { set_error("spq_prepare_f16x2: LoRA rank %lld > 128 unsupported", (long long)r); return SPQ_ERR_UNSUPPORTED; }
+  const PrepLayout P = make_prep_layout(N, K, r);
+  if (w_prep_bytes < P.total || !aligned16(w_prep)) { set_error("spq_prepare_f16x2: buffer too small (%zu < %zu)", w_prep_bytes, P.total); return SPQ_ERR_WORKSPACE; }
+  char* wp = (char*)w_prep;
+  PrepArgs a;
+  a.W = W; a.sw = sw; a.zw = zw; a.B = r > 0 ? B : nullptr; a.sb = sb; a.zb = zb; a.sx = sx;
+  a.Whi = (_Float16*)(wp + P.off_whi); a.Wlo = (_Float16*)(wp + P.off_wlo);
+  a.Bhi = P.Rp ? (_Float16*)(wp + P.off_bhi) : nullptr; a.Blo = P.Rp ? (_Float16*)(wp + P.off_blo) : nullptr;
+  a.rowscale = w_rowscale;
+  a.N = (int)N; a.K = (int)K; a.r = (int)r; a.Kp = (int)P.Kp; a.Rp = (int)P.Rp;
+  a.w_pc = w_per_channel; a.w_bits = w_bits; a.w_qtype = w_qtype; a.w_sym = w_symmetric;
+  a.b_pc = b_per_channel; a.b_bits = b_bits; a.b_qtype = b_qtype; a.b_sym = b_symmetric;
+  a.x_pc = x_per_channel; a.scaling = scaling;
+  prep_f16x2_kernel<<<(unsigned)P.Np, 256, 0, (hipStream_t)stream>>>(a);
+  return check_launch("spq_prepare_f16x2");
+}

@@ -80,6 +80,8 @@ class _Prepared:
 
     def __init__(self):
         self.sig = None
+        self.w = self.w_rowscale = self.a = self.b = None
+        self.r = 0
 
 
 def _sig(t):
@@ -122,6 +124,7 @@ class SPLinearWithLoRA(nn.Module):
         self.cache_operands = True                # reuse prepared operands in eval mode (see _operands)
         self._prepared = {}
         self._gemm_events = None                  # (hipEvent_t, hipEvent_t) around the dominant kernel, for bench.py
+        self._last_path = None                    # operand path of the most recent fused forward
 
     # ---- precision switching (lora.py:105-125): attribute flips only ---------------------------------------
     def set_precision(self, bits) -> int:
@@ -192,6 +195,7 @@ class SPLinearWithLoRA(nn.Module):
             raise ValueError(f"Unknown quantizer type: {qx.quantizer_type}. Supported types: 'minmax', 'log'")
         use_lora = (not self.calibration_mode) and lora.enabled and lora.scaling != 0
         prep = self._operands(key, qx, qw, lora, use_lora, quantize_input)
+        self._last_path = prep.path
 
         x2 = x.detach().contiguous().view(-1, self.in_features)
         M, K, N = x2.shape[0], self.in_features, self.out_features
@@ -226,13 +230,20 @@ class SPLinearWithLoRA(nn.Module):
         return y.view(*lead, N)
 
     # ---- weight-side operands --------------------------------------------------------------------------------
-    def _choose_path(self, qx, qw, lora, quantize_input):
-        if self.operand_path != _lib.PATH_AUTO:
-            return self.operand_path
-        return _lib.PATH_F32
+    def _choose_path(self, qx, qw, lora, use_lora, quantize_input):
+        """SPQ_PATH_F16X2 (exact integer levels x 2-limb fp16 weights) whenever the input quantizer allows it:
+        symmetric minmax, <= 12 bits, actually quantising; otherwise the always-valid fp32-MFMA path."""
+        f16_ok = (quantize_input and qx.quantizer_type == 'minmax' and qx.symmetric and 2 <= qx.num_bits <= 12
+                  and (not use_lora or lora.rank <= 128))
+        if self.operand_path == _lib.PATH_AUTO:
+            return _lib.PATH_F16X2 if f16_ok else _lib.PATH_F32
+        if self.operand_path == _lib.PATH_F16X2 and not f16_ok:
+            return _lib.PATH_F32            # e.g. calibration forwards (raw x) of a layer pinned to F16X2
+        return self.operand_path
 
     def _operands(self, key, qx, qw, lora, use_lora, quantize_input):
-        """FQ(W) [N,K], FQ(A)^T [r,K], FQ(B)^T [N,r] for the active bit-width.
+        """Weight-side GEMM operands for the active bit-width: FQ(W), FQ(A)^T, FQ(B)^T in the layout of the chosen
+        operand path (fp32, or 2-limb fp16 with the input scale folded in).
 
         The reference re-quantises these on every forward.  Here they are rebuilt on every call in training mode
         and, in eval mode, only when their inputs changed: tensor identity + autograd version of W/A/B and the
@@ -243,8 +254,10 @@ class SPLinearWithLoRA(nn.Module):
             raise RuntimeError(
                 f"Quantizer not calibrated. Please run calibration first for {qw.quantizer_type} quantizer.")
         W = self.linear.weight
-        path = self._choose_path(qx, qw, lora, quantize_input)
-        sig = [path, _sig(W), qw._epoch, _sig(qw.scale), _sig(qw.zero_point)]
+        path = self._choose_path(qx, qw, lora, use_lora, quantize_input)
+        sig = [path, use_lora, _sig(W), qw._epoch, _sig(qw.scale), _sig(qw.zero_point)]
+        if path == _lib.PATH_F16X2:
+            sig += [qx._epoch, _sig(qx.scale)]
         if use_lora:
             for q, t in ((lora.quantize_A, lora.lora_A), (lora.quantize_B, lora.lora_B)):
                 if not q.calibrated:
@@ -252,23 +265,49 @@ class SPLinearWithLoRA(nn.Module):
                         f"Quantizer not calibrated. Please run calibration first for {q.quantizer_type} quantizer.")
                 sig += [_sig(t), q._epoch, _sig(q.scale), _sig(q.zero_point)]
         sig = tuple(sig)
-        prep = self._prepared.get(key)
+        ckey = (key, path)
+        prep = self._prepared.get(ckey)
         if prep is not None and prep.sig == sig and self.cache_operands and not self.training:
             return prep
         prep = prep or _Prepared()
         prep.path, prep.w_rowscale = path, None
+        prep.r = lora.rank if use_lora else 0
         with torch.no_grad():
-            prep.w = qw(W.detach())                                            # spq_fakequant -> [N,K]
-            if use_lora:
-                prep.a = _fq_transposed(lora.quantize_A, lora.lora_A.detach())  # [r,K]
-                prep.b = _fq_transposed(lora.quantize_B, lora.lora_B.detach())  # [N,r]
-                prep.r = lora.rank
+            prep.a = _fq_transposed(lora.quantize_A, lora.lora_A.detach()) if use_lora else None   # [r,K]
+            if path == _lib.PATH_F32:
+                prep.w = qw(W.detach())                                                            # [N,K]
+                prep.b = _fq_transposed(lora.quantize_B, lora.lora_B.detach()) if use_lora else None  # [N,r]
             else:
-                prep.a = prep.b = None
-                prep.r = 0
+                self._prepare_f16x2(prep, qx, qw, lora, use_lora)
         prep.sig = sig
-        self._prepared[key] = prep
+        self._prepared[ckey] = prep
         return prep
+
+    def _prepare_f16x2(self, prep, qx, qw, lora, use_lora):
+        W = self.linear.weight.detach().contiguous()
+        N, K, r = self.out_features, self.in_features, prep.r
+        lib = _lib.load()
+        nbytes = lib.spq_prep_f16x2_bytes(N, K, r)
+        if getattr(prep, "w", None) is None or prep.w.dtype != torch.uint8 or prep.w.numel() < nbytes:
+            prep.w = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
+        n_pad = (N + 127) // 128 * 128
+        prep.w_rowscale = torch.empty(n_pad, dtype=torch.float32, device=W.device)
+        qb = lora.quantize_B if use_lora else None
+        B = lora.lora_B.detach().contiguous() if use_lora else None
+        for q, n_expected, what in ((qw, N, "weight"), (qb, N, "LoRA-B")):
+            if q is not None and q.scale.numel() not in (1, n_expected):
+                raise RuntimeError(f"{what} scale of shape {tuple(q.scale.shape)} does not fit {n_expected} output features")
+        with torch.cuda.device(W.device):
+            rc = lib.spq_prepare_f16x2(
+                W.data_ptr(), N, K, qw.scale.data_ptr(), qw.zero_point.data_ptr(), 1 if qw.scale.numel() > 1 else 0,
+                int(qw.num_bits), _lib.QTYPE_CODE[qw.quantizer_type], 1 if qw.symmetric else 0,
+                _lib.ptr(B), r, _lib.ptr(qb.scale) if qb else None, _lib.ptr(qb.zero_point) if qb else None,
+                (1 if qb.scale.numel() > 1 else 0) if qb else 0, int(qb.num_bits) if qb else 0,
+                _lib.QTYPE_CODE[qb.quantizer_type] if qb else 0, (1 if qb.symmetric else 0) if qb else 1,
+                float(lora.scaling) if use_lora else 0.0, qx.scale.data_ptr(), 1 if qx.scale.numel() > 1 else 0,
+                prep.w.data_ptr(), prep.w.numel(), prep.w_rowscale.data_ptr(), _lib.stream_ptr(W.device))
+        _lib.check(rc, "spq_prepare_f16x2")
+        prep.b = prep.w      # LoRA-B limbs live inside the same buffer
 
 
 def _fq_transposed(q: LearnableFakeQuantize, t: torch.Tensor) -> torch.Tensor:

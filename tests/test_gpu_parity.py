@@ -115,10 +115,13 @@ def test_quantizer_case(pkg, name):
     check_levels(q, t["xt"].to(DEV), t["fq_xt"], t["lv_xt"], meta["qtype"], name)
 
 
+@pytest.mark.parametrize("path", ["auto", "f32"])
 @pytest.mark.parametrize("name", LAYER_CASES)
-def test_layer_case(pkg, name):
+def test_layer_case(pkg, name, path):
     meta, t = load_case(name)
-    layer, key = build_layer(pkg, meta, t)
+    if path == "f32" and meta["qtype"] != "minmax":
+        pytest.skip("log input quantizers always take the f32 path; covered by path=auto")
+    layer, key = build_layer(pkg, meta, t, {"auto": pkg._lib.PATH_AUTO, "f32": pkg._lib.PATH_F32}[path])
     lora = layer.lora_adapters[key]
     quants = {"qx": layer.quantizers_input[key], "qw": layer.quantizers_weight[key], "qA": lora.quantize_A,
               "qB": lora.quantize_B}
@@ -157,6 +160,8 @@ def test_layer_case(pkg, name):
         layer.calibration_mode = False
         y2d = layer(t["x2"].reshape(-1, meta["K"])[:40].contiguous().to(DEV))
     assert tuple(y2.shape) == tuple(t["y_x2"].shape) and tuple(y2d.shape) == tuple(t["y_2d"].shape)
+    want = pkg._lib.PATH_F16X2 if (path == "auto" and qt == "minmax" and meta["bits"] <= 12) else pkg._lib.PATH_F32
+    assert layer._last_path == want, (layer._last_path, want)
     tol = 1e-5 if qt == "minmax" else 2e-5   # log: +1 ulp on ~2% of dequantised operands, see DESIGN.md
     assert_close_y(y2, t["y_x2"], f"{name}.y_x2", tol)
     assert_close_y(y0, t["y_x0"], f"{name}.y_x0", tol)
@@ -222,7 +227,8 @@ def test_error_behaviour(pkg):
         assert torch.allclose(layer(x), torch.nn.functional.linear(x, layer.linear.weight, layer.linear.bias))
 
 
-def test_headline_shape_against_oracle(pkg):
+@pytest.mark.parametrize("path", ["f16x2", "f32"])
+def test_headline_shape_against_oracle(pkg, path):
     """BASELINE headline: c_fc 768->3072, 4-bit minmax per-channel, r=64, batch 8 x seq 1024."""
     from oracle import ref_cpu as O
     M, K, N, r, bits = 8192, 768, 3072, 64, 4
@@ -234,6 +240,7 @@ def test_headline_shape_against_oracle(pkg):
         layer.lora_adapters["4bit"].lora_A.copy_(A); layer.lora_adapters["4bit"].lora_B.copy_(B)
     layer = layer.to(DEV).eval()
     layer.set_precision(bits)
+    layer.operand_path = {"f16x2": pkg._lib.PATH_F16X2, "f32": pkg._lib.PATH_F32}[path]
     pkg.calibrate_layer(layer, bits, [x0.to(DEV), x1.to(DEV)])
     assert torch.equal(layer.quantizers_input["4bit"].scale.cpu(), ol.qx.scale)
     assert torch.equal(layer.quantizers_weight["4bit"].scale.cpu(), ol.qw.scale)
@@ -241,5 +248,11 @@ def test_headline_shape_against_oracle(pkg):
     assert torch.equal(lv, ol.qx.levels(x0).to(torch.int32))
     with torch.no_grad():
         y = layer(x0.to(DEV))
-    worst = assert_close_y(y, ol.forward(x0), "headline y", 1e-5)
-    print(f"headline parity: max err/bound = {worst:.3f}")
+    assert layer._last_path == layer.operand_path
+    y_ref = ol.forward(x0)
+    worst = assert_close_y(y, y_ref, "headline y", 1e-5)
+    # size-independent property: the op is linear in the bias and exactly reproducible run to run
+    with torch.no_grad():
+        y_again = layer(x0.to(DEV))
+    assert torch.equal(y, y_again), "forward is not deterministic"
+    print(f"headline parity ({path}): max err/bound = {worst:.3f}")
