@@ -369,98 +369,169 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// DIAG bit mask (tools/gemm_bench only; the library instantiates 0): 1 = no global->LDS copies after the first stage,
+// 2 = no MFMA / fragment reads, 4 = no epilogue stores, 8 = MFMAs on stale registers (no fragment reads)
+//
+// Persistent: one workgroup per CU walks tiles p = blockIdx.x + i*gridDim.x.  Per 64-deep stage every wave issues its
+// share of the NEXT stage's global->LDS copies in four pairs, one pair behind each MFMA block, so the copy issue
+// (tens of cycles per 1-KB piece) runs while the matrix pipe drains that block instead of ahead of it.  The first
+// stage of the next tile is issued during the last stage of the current one, so the epilogue (accumulators -> LDS
+// transpose -> 16-byte stores of whole 128-B lines) overlaps that copy and the stores overlap the next tile's MFMAs.
+template <int DIAG>
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(GemmF16Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
+  const int l31 = lane & 31, h = lane >> 5;
 
-  // XCD-aware tile order (speed only): the workgroups of one XCD walk a contiguous run of tiles, N fastest.
   const int nwg = g.tiles_m * g.tiles_n;
-  const int orig = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int bm = (wgid / g.tiles_n) * GM;
-  const int bn = (wgid % g.tiles_n) * GN;
-
   const int nl = (g.Rp / GK) * 2;           // LoRA stages: per 64-wide block of r: (thi x {Bhi,Blo}), (tlo x {Bhi})
   const int T = nl + g.Kp / GK;
 
-  // per-lane source coordinates of one 1-KB glds piece: 8 rows x 8 chunks
+  // XCD-aware tile order (speed only).  Position p -> tile: the positions of one XCD (p % 8, observed round-robin
+  // placement) map to a contiguous run of tiles, and that run walks the tile grid in bands of 8 tile-rows, column by
+  // column, so the ~32 tiles an XCD has in flight form a compact patch (8 row panels x 4 column panels: A 3 MB +
+  // B 1.5 MB, inside its 4 MB L2).
+  auto tile_of = [&](int p, int& bm, int& bn) {
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = p & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (p >> 3);
+    constexpr int GROUP_M = 8;
+    const int band = wgid / (GROUP_M * g.tiles_n);
+    const int band_rows = min(GROUP_M, g.tiles_m - band * GROUP_M);
+    const int in_band = wgid - band * GROUP_M * g.tiles_n;
+    bm = (band * GROUP_M + in_band % band_rows) * GM;
+    bn = (in_band / band_rows) * GN;
+  };
+
+  // ---- global -> LDS copy pieces.  A piece = 1 KB = 8 rows x 8 chunks of 16 B; lane -> (row = lane>>3, chunk = lane&7)
+  // wave w issues A pieces 4w..4w+3 and B pieces 2w, 2w+1 of each limb.  Source chunk = chunk ^ ((row>>1)&7) (swz).
   const int prow = lane >> 3, pchunk = lane & 7;
+  int a_src[4], b_src[2];                     // per-lane element offsets inside a [rows][ld] panel, for ld = 1: row, col
+  int a_row[4], b_row[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a_row[i] = (4 * w + i) * 8 + prow; a_src[i] = swz(a_row[i], pchunk) * 8; }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { b_row[i] = (2 * w + i) * 8 + prow; b_src[i] = swz(b_row[i], pchunk) * 8; }
 
-  auto issue = [&](int t, int buf) {
-    char* sb = smem + buf * STAGE_BYTES;
-    const _Float16 *A, *Bh, *Bl;
-    int64_t lda, ldb; int k0; bool two;
+  struct StageSrc { const _Float16 *A, *Bh, *Bl; int lda, ldb, k0; bool two; };
+  auto stage_src = [&](int t) {
+    StageSrc s;
     if (t < nl) {
-      const int blk = t >> 1, which = t & 1;
-      A = which ? g.tlo : g.thi; lda = g.Rp; Bh = g.Bhi; Bl = g.Blo; ldb = g.Rp; k0 = blk * GK; two = (which == 0);
+      const int which = t & 1;
+      s.A = which ? g.tlo : g.thi; s.lda = g.Rp; s.Bh = g.Bhi; s.Bl = g.Blo; s.ldb = g.Rp; s.k0 = (t >> 1) * GK;
+      s.two = (which == 0);
     } else {
-      A = g.qx; lda = g.Kp; Bh = g.Whi; Bl = g.Wlo; ldb = g.Kp; k0 = (t - nl) * GK; two = true;
+      s.A = g.qx; s.lda = g.Kp; s.Bh = g.Whi; s.Bl = g.Wlo; s.ldb = g.Kp; s.k0 = (t - nl) * GK; s.two = true;
     }
-    // A: 32 pieces of 8 rows; wave w issues pieces 4w..4w+3
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int piece = 4 * w + i;
-      const int row = piece * 8 + prow;
-      const _Float16* src = A + (int64_t)(bm + row) * lda + k0 + swz(row, pchunk) * 8;
-      glds16(src, sb + piece * 1024);
-    }
-    // B: 16 pieces per limb; wave w issues pieces 2w, 2w+1 of each limb
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int piece = 2 * w + i;
-      const int row = piece * 8 + prow;
-      const int64_t off = (int64_t)(bn + row) * ldb + k0 + swz(row, pchunk) * 8;
-      glds16(Bh + off, sb + STAGE_A + piece * 1024);
-      if (two) glds16(Bl + off, sb + STAGE_A + STAGE_B + piece * 1024);
-    }
+    return s;
   };
-
-  f32x16 acc[2][2];
+  // pair j (0..3) of the 8 copies a wave owes to a stage: j<2 -> two A pieces; j==2 -> A piece 2w.. no: see below
+  //   pair 0: A[0], A[1]   pair 1: A[2], A[3]   pair 2: Bh[0], Bh[1]   pair 3: Bl[0], Bl[1] (skipped for one-limb stages)
+  auto issue_pair = [&](const StageSrc& s, int bm, int bn, char* sb, int j) {
+    if (j < 2) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int l31 = lane & 31, h = lane >> 5;
-  auto compute = [&](int buf, bool two) {
-    const char* sa = smem + buf * STAGE_BYTES;
-    const char* sbh = sa + STAGE_A;
-    const char* sbl = sbh + STAGE_B;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {                       // four k16 blocks of the 64-deep stage
-      const int c = 2 * s + h;
-      f16x8 af[2], bh[2], bl[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int ra = wm * 64 + t * 32 + l31;
-        af[t] = *reinterpret_cast<const f16x8*>(sa + ra * 128 + swz(ra, c) * 16);
-        const int rb = wn * 64 + t * 32 + l31;
-        bh[t] = *reinterpret_cast<const f16x8*>(sbh + rb * 128 + swz(rb, c) * 16);
-        if (two) bl[t] = *reinterpret_cast<const f16x8*>(sbl + rb * 128 + swz(rb, c) * 16);
+      for (int i = 0; i < 2; ++i) {
+        const int ii = 2 * j + i;
+        glds16(s.A + (int64_t)(bm + a_row[ii]) * s.lda + s.k0 + a_src[ii], sb + (4 * w + ii) * 1024);
       }
-      __builtin_amdgcn_s_setprio(1);
+    } else if (j == 2) {
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int i = 0; i < 2; ++i)
+        glds16(s.Bh + (int64_t)(bn + b_row[i]) * s.ldb + s.k0 + b_src[i], sb + STAGE_A + (2 * w + i) * 1024);
+    } else if (s.two) {
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-          if (two) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-        }
-      __builtin_amdgcn_s_setprio(0);
+      for (int i = 0; i < 2; ++i)
+        glds16(s.Bl + (int64_t)(bn + b_row[i]) * s.ldb + s.k0 + b_src[i], sb + STAGE_A + STAGE_B + (2 * w + i) * 1024);
     }
   };
 
-  issue(0, 0);
-  __syncthreads();                                      // drains the LDS-DMA (vmcnt(0)) and joins the waves
-  for (int t = 0; t < T; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < T) issue(t + 1, buf ^ 1);               // next stage lands under this stage's MFMAs
-    if (t == nl && nl > 0) {                            // LoRA partial sums -> units of the base sum: * 2^-g[m]
+  // ---- fragments: per-lane LDS byte offsets: row part + swizzled chunk of k16 block s (chunk 2s+h)
+  const int sx7 = (l31 >> 1) & 7;                          // == ((row >> 1) & 7) for every fragment row of this lane
+  const int fa_row = (wm * 64 + l31) * 128;                // + tm * 4096
+  const int fb_row = STAGE_A + (wn * 64 + l31) * 128;      // + tn * 4096 (+ STAGE_B for the lo limb)
+  int koff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) koff[s] = ((2 * s + h) ^ sx7) * 16;
+
+  struct Frags { f16x8 a[2], bh[2], bl[2]; };
+  f32x16 acc[2][2];
+  auto load_frags = [&](Frags& f, const char* sb, int s, bool two) {
+    if (DIAG & 8) {
+      asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.bh[0]), "+v"(f.bh[1]), "+v"(f.bl[0]), "+v"(f.bl[1]));
+      return;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f.a[t] = *reinterpret_cast<const f16x8*>(sb + fa_row + t * 4096 + koff[s]);
+      f.bh[t] = *reinterpret_cast<const f16x8*>(sb + fb_row + t * 4096 + koff[s]);
+      if (two) f.bl[t] = *reinterpret_cast<const f16x8*>(sb + fb_row + STAGE_B + t * 4096 + koff[s]);
+    }
+  };
+  auto mfma_block = [&](const Frags& f, bool two) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
+        if (two) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm], f.bl[tn], acc[tm][tn], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // one stage: compute from buffer `cur`; meanwhile copy stage `nxt` (of tile nbm,nbn) into the other buffer
+  auto stage = [&](int cur, bool two, bool have_next, const StageSrc& nxt, int nbm, int nbn) {
+    const char* sb = smem + cur * STAGE_BYTES;
+    char* nb = smem + (cur ^ 1) * STAGE_BYTES;
+    const bool cp = have_next && !(DIAG & 1);
+    Frags f0, f1;
+    if (DIAG & 8) { f0.a[0] = f0.a[1] = f0.bh[0] = f0.bh[1] = f0.bl[0] = f0.bl[1] = (f16x8)(_Float16)1.f; f1 = f0; }
+    if (!(DIAG & 2)) {
+      load_frags(f0, sb, 0, two);
+      load_frags(f1, sb, 1, two); mfma_block(f0, two); if (cp) issue_pair(nxt, nbm, nbn, nb, 0);
+      load_frags(f0, sb, 2, two); mfma_block(f1, two); if (cp) issue_pair(nxt, nbm, nbn, nb, 1);
+      load_frags(f1, sb, 3, two); mfma_block(f0, two); if (cp) issue_pair(nxt, nbm, nbn, nb, 2);
+      mfma_block(f1, two);                             if (cp) issue_pair(nxt, nbm, nbn, nb, 3);
+    } else if (cp) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) issue_pair(nxt, nbm, nbn, nb, j);
+    }
+    __syncthreads();                                    // drains the LDS-DMA of the next stage (vmcnt(0)), joins the waves
+  };
+
+  int p = blockIdx.x;
+  if (p >= nwg) return;
+  int bm, bn;
+  tile_of(p, bm, bn);
+  int base = 0;                                         // buffer of the current tile's stage 0
+  {
+    const StageSrc s0 = stage_src(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_pair(s0, bm, bn, smem, j);
+  }
+  __syncthreads();
+
+  while (true) {
+    const int pn = p + gridDim.x;
+    const bool more = pn < nwg;
+    int nbm = 0, nbn = 0;
+    if (more) tile_of(pn, nbm, nbn);
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // LoRA segment first, so that its per-row scale applies to it alone
+    for (int t = 0; t < nl; t += 2) {
+      stage((base + t) & 1, true, true, stage_src(t + 1), bm, bn);
+      const bool last = (t + 2 == T);                   // only when there is no base segment (never in practice)
+      stage((base + t + 1) & 1, false, !last || more, stage_src(last ? 0 : t + 2), last ? nbm : bm, last ? nbn : bn);
+    }
+    if (nl > 0) {                                       // LoRA partial sums -> units of the base sum: * 2^-g[m]
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -470,24 +541,49 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(GemmF16Args g) {
           acc[tm][0][e] *= ri; acc[tm][1][e] *= ri;
         }
     }
-    if (t < nl && (t & 1)) compute(buf, false); else compute(buf, true);
-    __syncthreads();
-  }
+    for (int t = nl; t < T; ++t) {
+      const bool last = (t + 1 == T);
+      stage((base + t) & 1, true, !last || more, stage_src(last ? 0 : t + 1), last ? nbm : bm, last ? nbn : bn);
+    }
 
-  // epilogue: y = acc * 2^-e[n] + bias[n]; C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // ---- epilogue: y = acc * 2^-e[n] + bias[n].  The buffer of the last stage is free (the next tile's stage 0 is
+    // landing in the other one): each wave transposes one 32x32 accumulator tile at a time through its private 4.5 KB
+    // slice (row stride 144 B) and stores 16 B per lane: 8 rows x 128 B per instruction, whole lines.
+    {
+      char* eb = smem + ((base + T - 1) & 1) * STAGE_BYTES + w * (32 * 144);
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int n = bn + wn * 64 + tn * 32 + l31;
-    if (n >= g.N) continue;
-    const float rs = g.rowscale[n];
-    const float bv = g.bias ? g.bias[n] : 0.f;
+      for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+        for (int tn = 0; tn < 2; ++tn) {
+          // C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = bm + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m < g.M) g.y[(int64_t)m * g.N + n] = acc[tm][tn][e] * rs + bv;
-      }
+          for (int e = 0; e < 16; ++e)
+            *reinterpret_cast<float*>(eb + ((e & 3) + 8 * (e >> 2) + 4 * h) * 144 + l31 * 4) = acc[tm][tn][e];
+          const int c4 = (lane & 7) * 4;                                   // 8 lanes x 16 B per 128-B row
+          const int n = bn + wn * 64 + tn * 32 + c4;
+          float4 rs = make_float4(0.f, 0.f, 0.f, 0.f), bv = rs;
+          const bool n_ok = n < g.N;                                       // N % 4 == 0 is required by the launcher
+          if (n_ok) {
+            rs = *reinterpret_cast<const float4*>(g.rowscale + n);
+            if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + n);
+          }
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + (lane >> 3);
+            const float4 v = *reinterpret_cast<const float4*>(eb + r * 144 + c4 * 4);
+            const int m = bm + wm * 64 + tm * 32 + r;
+            if (n_ok && m < g.M && (!(DIAG & 4) || v.x == 12345.f)) {
+              float4 o;
+              o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
+              *reinterpret_cast<float4*>(g.y + (int64_t)m * g.N + n) = o;
+            }
+          }
+        }
+    }
+    if (!more) break;
+    __syncthreads();                                    // every wave is done with the epilogue slice of this buffer
+    base = (base + T) & 1;
+    p = pn; bm = nbm; bn = nbn;
   }
 }
 
@@ -508,7 +604,19 @@ static PrepLayout make_prep_layout(int64_t N, int64_t K, int64_t r) {
 }
 
 static bool f16x2_shape_ok(int64_t M, int64_t K, int64_t N, int64_t r) {
-  return r <= 128 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30);
+  return r <= 128 && (N % 4 == 0) && M < (1 << 30) && N < (1 << 30) && K < (1 << 30);
+}
+
+// persistent grid: one workgroup per CU (a multiple of 8 so that p % 8 stays the XCD label across iterations)
+unsigned gemm_grid(int ntiles) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) cus = n / 8 * 8;
+    else cus = 256;
+  }
+  return (unsigned)(ntiles < cus ? ntiles : cus);
 }
 
 int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
@@ -518,7 +626,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     return SPQ_ERR_UNSUPPORTED;
   }
   if (!f16x2_shape_ok(a->M, a->K, a->N, a->r)) {
-    set_error("spq_linear_lora_fwd: SPQ_PATH_F16X2 supports LoRA rank <= 128 (got %lld)", (long long)a->r);
+    set_error("spq_linear_lora_fwd: SPQ_PATH_F16X2 needs LoRA rank <= 128 and N %% 4 == 0 (got r=%lld N=%lld)", (long long)a->r, (long long)a->N);
     return SPQ_ERR_UNSUPPORTED;
   }
   SPQ_REQUIRE(a->w_rowscale, "spq_linear_lora_fwd: w_rowscale missing for SPQ_PATH_F16X2");
@@ -548,13 +656,13 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   g.tiles_m = (int)(L.Mp / GM); g.tiles_n = (int)(P.Np / GN);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16x2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        2 * STAGE_BYTES);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %d B): %s", 2 * STAGE_BYTES, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
     attr_set = true;
   }
   if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
-  gemm_f16x2_kernel<<<(unsigned)(g.tiles_m * g.tiles_n), 512, 2 * STAGE_BYTES, st>>>(g);
+  gemm_f16x2_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), 512, 2 * STAGE_BYTES, st>>>(g);
   if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
   return check_launch("spq_linear_lora_fwd(gemm_f16x2)");
 }
@@ -577,7 +685,7 @@ extern "C" int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const flo
   SPQ_REQUIRE(N > 0 && K > 0 && r >= 0, "spq_prepare_f16x2: bad shape");
   SPQ_REQUIRE(r == 0 || (B && sb && zb), "spq_prepare_f16x2: LoRA-B operands missing");
   SPQ_REQUIRE(w_bits >= 1 && b_bits >= 0, "spq_prepare_f16x2: bad bit-width");
-  if (!f16x2_shape_ok(1, K, N, r)) { set_error("spq_prepare_f16x2: LoRA rank %lld > 128 unsupported", (long long)r); return SPQ_ERR_UNSUPPORTED; }
+  if (!f16x2_shape_ok(1, K, N, r)) { set_error("spq_prepare_f16x2: needs LoRA rank <= 128 and N %% 4 == 0 (got r=%lld N=%lld)", (long long)r, (long long)N); return SPQ_ERR_UNSUPPORTED; }
   const PrepLayout P = make_prep_layout(N, K, r);
   if (w_prep_bytes < P.total || !aligned16(w_prep)) { set_error("spq_prepare_f16x2: buffer too small (%zu < %zu)", w_prep_bytes, P.total); return SPQ_ERR_WORKSPACE; }
   char* wp = (char*)w_prep;

@@ -1,0 +1,49 @@
+// Stand-alone timing harness for the f16x2 contraction kernel (kernel tuning only; not part of the product).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off tools/gemm_bench.hip -o tools/gemm_bench
+#include <stdarg.h>
+#include <vector>
+#include <random>
+#include "../llm-qat-on-gpt2_amd/csrc/spq_f16x2.hip"
+namespace spq {
+void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fprintf(stderr, "\n"); }
+int check_launch(const char* what) { hipError_t e = hipGetLastError(); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return -2; } return 0; }
+}
+using namespace spq;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int DIAG>
+float run(const GemmF16Args& g, int iters) {
+  hipFuncSetAttribute((const void*)gemm_f16x2_kernel<DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 5; ++i) gemm_f16x2_kernel<DIAG><<<gemm_grid(g.tiles_m * g.tiles_n), 512, 2 * STAGE_BYTES>>>(g);
+  hipEventRecord(a);
+  for (int i = 0; i < iters; ++i) gemm_f16x2_kernel<DIAG><<<gemm_grid(g.tiles_m * g.tiles_n), 512, 2 * STAGE_BYTES>>>(g);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  return ms / iters * 1e3f;
+}
+
+int main(int argc, char** argv) {
+  const int M = 8192, N = 3072, K = 768, R = 64;
+  std::mt19937 rng(1);
+  auto fill = [&](size_t n, int kind) {
+    std::vector<_Float16> h(n);
+    std::uniform_int_distribution<int> lv(-7, 7); std::normal_distribution<float> nd(0.f, 3000.f);
+    for (auto& v : h) v = kind == 0 ? (_Float16)(float)lv(rng) : (_Float16)nd(rng);
+    _Float16* d; hipMalloc(&d, n * 2); hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice); return d;
+  };
+  GemmF16Args g;
+  g.qx = fill((size_t)M * K, 0); g.thi = fill((size_t)M * R, 1); g.tlo = fill((size_t)M * R, 1);
+  g.Whi = fill((size_t)N * K, 1); g.Wlo = fill((size_t)N * K, 1); g.Bhi = fill((size_t)N * R, 1); g.Blo = fill((size_t)N * R, 1);
+  float *ri, *rs, *bias, *y;
+  hipMalloc(&ri, M * 4); hipMalloc(&rs, N * 4); hipMalloc(&bias, N * 4); hipMalloc(&y, (size_t)M * N * 4);
+  hipMemset(ri, 0, M * 4); hipMemset(rs, 0, N * 4); hipMemset(bias, 0, N * 4);
+  g.rowinv = ri; g.rowscale = rs; g.bias = bias; g.y = y; g.M = M; g.N = N; g.Kp = K; g.Rp = R;
+  g.tiles_m = M / GM; g.tiles_n = N / GN;
+  const int iters = 50;
+  for (int rep = 0; rep < 2; ++rep) {
+    printf("full %.1f | no-loads %.1f | no-compute %.1f | no-stores %.1f | no-loads,no-stores %.1f | mfma-only(no loads/frag reads/stores) %.1f | stores-only %.1f us\n",
+           run<0>(g, iters), run<1>(g, iters), run<2>(g, iters), run<4>(g, iters), run<5>(g, iters), run<13>(g, iters), run<3>(g, iters));
+  }
+  return 0;
+}
