@@ -353,15 +353,19 @@ struct GemmF16Args {
   float* y;
   int M, N, Kp, Rp;                         // Rp = 0: no LoRA
   int tiles_m, tiles_n;
+  unsigned long long* dbg;                  // tools/gemm_bench only (DIAG & 16): per-workgroup clock stamps
 };
 
+// ---- LDS: two 64-deep stage buffers (A 256x64 f16 = 32 KB, B hi/lo 128x64 f16 = 16 KB each) + a dedicated
+// epilogue region.  128-byte rows of eight 16-B chunks; chunk c of row r is stored at chunk position c ^ ((r>>1)&7):
+// the 16 lanes of every ds_read_b128 group (row = lane&31 per fragment) hit 16 distinct 16-B slots of the bank row.
 constexpr int STAGE_A = GM * GK * 2;               // 32 KB
 constexpr int STAGE_B = GN * GK * 2;               // 16 KB per limb
 constexpr int STAGE_BYTES = STAGE_A + 2 * STAGE_B; // 64 KB
+constexpr int EPI_WAVE = 16 * 144;                 // 16 rows x (32 floats + pad) per compute wave
+constexpr int GEMM_LDS = 2 * STAGE_BYTES + 8 * EPI_WAVE;   // 128 KB + 18 KB
+constexpr int GEMM_THREADS = 512;                  // 8 waves = 4(M) x 2(N), 64x64 outputs each
 
-// LDS image of a [rows][64 f16] tile: 128-B rows of eight 16-B chunks; chunk c of row r is stored at chunk position
-// c ^ ((r>>1)&7).  With row = lane&31 per fragment read, the 16 lanes of every ds_read_b128 group then hit 16
-// distinct 16-B slots of the 256-B bank row (rows of equal parity differ in (r>>1)&7): conflict-free.
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -370,15 +374,24 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 
 // DIAG bit mask (tools/gemm_bench only; the library instantiates 0): 1 = no global->LDS copies after the first stage,
-// 2 = no MFMA / fragment reads, 4 = no epilogue stores, 8 = MFMAs on stale registers (no fragment reads)
+// 2 = no MFMA / fragment reads, 4 = no epilogue stores, 8 = MFMAs on stale registers (no fragment reads),
+// 16 = clock stamps, 32 = double MFMA work, 64 = no barriers
 //
-// Persistent: one workgroup per CU walks tiles p = blockIdx.x + i*gridDim.x.  Per 64-deep stage every wave issues its
-// share of the NEXT stage's global->LDS copies in four pairs, one pair behind each MFMA block, so the copy issue
-// (tens of cycles per 1-KB piece) runs while the matrix pipe drains that block instead of ahead of it.  The first
-// stage of the next tile is issued during the last stage of the current one, so the epilogue (accumulators -> LDS
-// transpose -> 16-byte stores of whole 128-B lines) overlaps that copy and the stores overlap the next tile's MFMAs.
+// Structure.  Persistent: one workgroup per CU walks tiles p = blockIdx.x + i*gridDim.x; the sequence of 64-deep
+// stages S_0, S_1, ... runs straight through tile boundaries, stage S_i in buffer i&1.  Per stage:
+//     every wave issues its 8 copy pieces of S_{i+1} (global -> LDS, 16 B per lane) into the other buffer
+//     raw s_barrier (no counter wait)            <- measured on gfx950 (tools/overlap_probe): a wave streaming MFMAs
+//                                                   starves the other waves of its SIMD of issue slots, so a copy that
+//                                                   is not issued BEFORE the MFMA streams start is issued after them
+//     MFMAs of S_i; fragment reads of k16 block s+1 are issued ahead of the MFMAs of block s
+//     s_waitcnt vmcnt(0) + s_barrier             <- S_{i+1} has landed, buffer of S_i is free
+// After a tile's last stage the waves transpose their accumulators through private LDS slices and store whole
+// 128-B lines; those stores drain under the next tile's first stage.
+// LoRA stages come first in a tile: (thi x {Bhi,Blo}) then (tlo x {Bhi}) per 64-wide block of r, then the partial
+// sums are multiplied by 2^-g[m] and the base stages (qx x {Whi,Wlo}) accumulate on top.
+#define SPQ_SYNC() do { if (!(DIAG & 64)) __syncthreads(); } while (0)
 template <int DIAG>
-__global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(GemmF16Args g) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_kernel(GemmF16Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -386,13 +399,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(GemmF16Args g) {
   const int l31 = lane & 31, h = lane >> 5;
 
   const int nwg = g.tiles_m * g.tiles_n;
-  const int nl = (g.Rp / GK) * 2;           // LoRA stages: per 64-wide block of r: (thi x {Bhi,Blo}), (tlo x {Bhi})
-  const int T = nl + g.Kp / GK;
+  const int nl = (g.Rp / GK) * 2;           // LoRA stages per tile
+  const int T = nl + g.Kp / GK;             // stages per tile
+  const int gstride = (int)gridDim.x;
 
-  // XCD-aware tile order (speed only).  Position p -> tile: the positions of one XCD (p % 8, observed round-robin
-  // placement) map to a contiguous run of tiles, and that run walks the tile grid in bands of 8 tile-rows, column by
-  // column, so the ~32 tiles an XCD has in flight form a compact patch (8 row panels x 4 column panels: A 3 MB +
-  // B 1.5 MB, inside its 4 MB L2).
+  // XCD-aware tile order (speed only): positions of one XCD (p % 8, observed round-robin placement) map to a
+  // contiguous run of tiles that walks the tile grid in bands of 8 tile-rows, column by column, so the ~32 tiles an
+  // XCD has in flight form a compact patch (8 row panels x 4 column panels) that fits its 4 MB L2.
   auto tile_of = [&](int p, int& bm, int& bn) {
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = p & 7;
     const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (p >> 3);
@@ -404,45 +417,40 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(GemmF16Args g) {
     bn = (in_band / band_rows) * GN;
   };
 
-  // ---- global -> LDS copy pieces.  A piece = 1 KB = 8 rows x 8 chunks of 16 B; lane -> (row = lane>>3, chunk = lane&7)
-  // wave w issues A pieces 4w..4w+3 and B pieces 2w, 2w+1 of each limb.  Source chunk = chunk ^ ((row>>1)&7) (swz).
-  const int prow = lane >> 3, pchunk = lane & 7;
-  int a_src[4], b_src[2];                     // per-lane element offsets inside a [rows][ld] panel, for ld = 1: row, col
-  int a_row[4], b_row[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { a_row[i] = (4 * w + i) * 8 + prow; a_src[i] = swz(a_row[i], pchunk) * 8; }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { b_row[i] = (2 * w + i) * 8 + prow; b_src[i] = swz(b_row[i], pchunk) * 8; }
+  int p = blockIdx.x;
+  if (p >= nwg) return;
+  int bm, bn;
+  tile_of(p, bm, bn);
+  unsigned long long t0c = 0, t0r = 0;
+  if (DIAG & 16) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
 
-  struct StageSrc { const _Float16 *A, *Bh, *Bl; int lda, ldb, k0; bool two; };
-  auto stage_src = [&](int t) {
-    StageSrc s;
+  // ---- copies.  A piece = 1 KB = 8 rows x 8 chunks of 16 B; lane -> (row = lane>>3, chunk position = lane&7); the
+  // source chunk is position ^ ((row>>1)&7).  Wave w owns A pieces 4w..4w+3 and pieces 2w, 2w+1 of each B limb.
+  const int prow = lane >> 3, pchunk = lane & 7;
+  int a_row[4], a_col[4], b_row[2], b_col[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a_row[i] = (4 * w + i) * 8 + prow; a_col[i] = swz(a_row[i], pchunk) * 8; }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { b_row[i] = (2 * w + i) * 8 + prow; b_col[i] = swz(b_row[i], pchunk) * 8; }
+  auto issue = [&](int t, int tbm, int tbn, int buf) {
+    char* sb = smem + buf * STAGE_BYTES;
+    const _Float16 *A, *Bh, *Bl; int lda, ldb, k0; bool two;
     if (t < nl) {
       const int which = t & 1;
-      s.A = which ? g.tlo : g.thi; s.lda = g.Rp; s.Bh = g.Bhi; s.Bl = g.Blo; s.ldb = g.Rp; s.k0 = (t >> 1) * GK;
-      s.two = (which == 0);
+      A = which ? g.tlo : g.thi; lda = g.Rp; Bh = g.Bhi; Bl = g.Blo; ldb = g.Rp; k0 = (t >> 1) * GK; two = !which;
     } else {
-      s.A = g.qx; s.lda = g.Kp; s.Bh = g.Whi; s.Bl = g.Wlo; s.ldb = g.Kp; s.k0 = (t - nl) * GK; s.two = true;
+      A = g.qx; lda = g.Kp; Bh = g.Whi; Bl = g.Wlo; ldb = g.Kp; k0 = (t - nl) * GK; two = true;
     }
-    return s;
-  };
-  // pair j (0..3) of the 8 copies a wave owes to a stage: j<2 -> two A pieces; j==2 -> A piece 2w.. no: see below
-  //   pair 0: A[0], A[1]   pair 1: A[2], A[3]   pair 2: Bh[0], Bh[1]   pair 3: Bl[0], Bl[1] (skipped for one-limb stages)
-  auto issue_pair = [&](const StageSrc& s, int bm, int bn, char* sb, int j) {
-    if (j < 2) {
+    const _Float16* Ab = A + (int64_t)tbm * lda + k0;          // wave-uniform base, 32-bit per-lane offsets
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ii = 2 * j + i;
-        glds16(s.A + (int64_t)(bm + a_row[ii]) * s.lda + s.k0 + a_src[ii], sb + (4 * w + ii) * 1024);
-      }
-    } else if (j == 2) {
+    for (int i = 0; i < 4; ++i) glds16(Ab + (a_row[i] * lda + a_col[i]), sb + (4 * w + i) * 1024);
+    const _Float16* Bhb = Bh + (int64_t)tbn * ldb + k0;
+    const _Float16* Blb = Bl + (int64_t)tbn * ldb + k0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        glds16(s.Bh + (int64_t)(bn + b_row[i]) * s.ldb + s.k0 + b_src[i], sb + STAGE_A + (2 * w + i) * 1024);
-    } else if (s.two) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        glds16(s.Bl + (int64_t)(bn + b_row[i]) * s.ldb + s.k0 + b_src[i], sb + STAGE_A + STAGE_B + (2 * w + i) * 1024);
+    for (int i = 0; i < 2; ++i) {
+      const int off = b_row[i] * ldb + b_col[i];
+      glds16(Bhb + off, sb + STAGE_A + (2 * w + i) * 1024);
+      if (two) glds16(Blb + off, sb + STAGE_A + STAGE_B + (2 * w + i) * 1024);
     }
   };
 
@@ -469,7 +477,6 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(GemmF16Args g) {
     }
   };
   auto mfma_block = [&](const Frags& f, bool two) {
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -477,61 +484,48 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(GemmF16Args g) {
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
         if (two) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm], f.bl[tn], acc[tm][tn], 0, 0, 0);
       }
-    __builtin_amdgcn_s_setprio(0);
   };
-
-  // one stage: compute from buffer `cur`; meanwhile copy stage `nxt` (of tile nbm,nbn) into the other buffer
-  auto stage = [&](int cur, bool two, bool have_next, const StageSrc& nxt, int nbm, int nbn) {
+  // stage t of the current tile (buffer cur); first put the next stage (nt of tile nbm,nbn) in flight
+  auto stage = [&](int cur, bool two, bool have_next, int nt, int nbm, int nbn) {
+    if (have_next && !(DIAG & 1)) issue(nt, nbm, nbn, cur ^ 1);
+    if (!(DIAG & 64)) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // all copies issued; no counter wait
     const char* sb = smem + cur * STAGE_BYTES;
-    char* nb = smem + (cur ^ 1) * STAGE_BYTES;
-    const bool cp = have_next && !(DIAG & 1);
     Frags f0, f1;
     if (DIAG & 8) { f0.a[0] = f0.a[1] = f0.bh[0] = f0.bh[1] = f0.bl[0] = f0.bl[1] = (f16x8)(_Float16)1.f; f1 = f0; }
     if (!(DIAG & 2)) {
       load_frags(f0, sb, 0, two);
-      load_frags(f1, sb, 1, two); mfma_block(f0, two); if (cp) issue_pair(nxt, nbm, nbn, nb, 0);
-      load_frags(f0, sb, 2, two); mfma_block(f1, two); if (cp) issue_pair(nxt, nbm, nbn, nb, 1);
-      load_frags(f1, sb, 3, two); mfma_block(f0, two); if (cp) issue_pair(nxt, nbm, nbn, nb, 2);
-      mfma_block(f1, two);                             if (cp) issue_pair(nxt, nbm, nbn, nb, 3);
-    } else if (cp) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) issue_pair(nxt, nbm, nbn, nb, j);
+      load_frags(f1, sb, 1, two); mfma_block(f0, two);
+      load_frags(f0, sb, 2, two); mfma_block(f1, two);
+      load_frags(f1, sb, 3, two); mfma_block(f0, two);
+      mfma_block(f1, two);
+      if (DIAG & 32) { mfma_block(f0, two); mfma_block(f1, two); mfma_block(f0, two); mfma_block(f1, two); }
     }
-    __syncthreads();                                    // drains the LDS-DMA of the next stage (vmcnt(0)), joins the waves
+    SPQ_SYNC();                                            // vmcnt(0): my pieces of the next stage landed; barrier: all did
   };
 
-  int p = blockIdx.x;
-  if (p >= nwg) return;
-  int bm, bn;
-  tile_of(p, bm, bn);
-  int base = 0;                                         // buffer of the current tile's stage 0
-  {
-    const StageSrc s0 = stage_src(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) issue_pair(s0, bm, bn, smem, j);
-  }
-  __syncthreads();
-
+  issue(0, bm, bn, 0);
+  SPQ_SYNC();
+  int base = 0;                                          // buffer of the current tile's stage 0
   while (true) {
-    const int pn = p + gridDim.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+
+    const int pn = p + gstride;
     const bool more = pn < nwg;
     int nbm = 0, nbn = 0;
     if (more) tile_of(pn, nbm, nbn);
 
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
     // LoRA segment first, so that its per-row scale applies to it alone
     for (int t = 0; t < nl; t += 2) {
-      stage((base + t) & 1, true, true, stage_src(t + 1), bm, bn);
-      const bool last = (t + 2 == T);                   // only when there is no base segment (never in practice)
-      stage((base + t + 1) & 1, false, !last || more, stage_src(last ? 0 : t + 2), last ? nbm : bm, last ? nbn : bn);
+      stage((base + t) & 1, true, true, t + 1, bm, bn);
+      const bool last = (t + 2 == T);
+      stage((base + t + 1) & 1, false, !last || more, last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
     }
-    if (nl > 0) {                                       // LoRA partial sums -> units of the base sum: * 2^-g[m]
+    if (nl > 0) {                                        // LoRA partial sums -> units of the base sum: * 2^-g[m]
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -543,49 +537,57 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(GemmF16Args g) {
     }
     for (int t = nl; t < T; ++t) {
       const bool last = (t + 1 == T);
-      stage((base + t) & 1, true, !last || more, stage_src(last ? 0 : t + 1), last ? nbm : bm, last ? nbn : bn);
+      stage((base + t) & 1, true, !last || more, last ? 0 : t + 1, last ? nbm : bm, last ? nbn : bn);
     }
 
-    // ---- epilogue: y = acc * 2^-e[n] + bias[n].  The buffer of the last stage is free (the next tile's stage 0 is
-    // landing in the other one): each wave transposes one 32x32 accumulator tile at a time through its private 4.5 KB
-    // slice (row stride 144 B) and stores 16 B per lane: 8 rows x 128 B per instruction, whole lines.
+    // ---- epilogue: y = acc * 2^-e[n] + bias[n].  Each wave transposes 16 rows x 32 cols at a time through its
+    // private LDS slice (row stride 144 B) and stores 16 B per lane: 8 rows x 128 B per instruction, whole lines.
     {
-      char* eb = smem + ((base + T - 1) & 1) * STAGE_BYTES + w * (32 * 144);
+      char* eb = smem + 2 * STAGE_BYTES + w * EPI_WAVE;
+      const int c4 = (lane & 7) * 4;                     // 8 lanes x 16 B per 128-B row
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int tn = 0; tn < 2; ++tn) {
+        const int n = bn + wn * 64 + tn * 32 + c4;
+        float4 rs = make_float4(0.f, 0.f, 0.f, 0.f), bv = rs;
+        const bool n_ok = n < g.N;                       // N % 4 == 0 is required by the launcher
+        if (n_ok) {
+          rs = *reinterpret_cast<const float4*>(g.rowscale + n);
+          if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + n);
+        }
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          // C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+        for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-          for (int e = 0; e < 16; ++e)
-            *reinterpret_cast<float*>(eb + ((e & 3) + 8 * (e >> 2) + 4 * h) * 144 + l31 * 4) = acc[tm][tn][e];
-          const int c4 = (lane & 7) * 4;                                   // 8 lanes x 16 B per 128-B row
-          const int n = bn + wn * 64 + tn * 32 + c4;
-          float4 rs = make_float4(0.f, 0.f, 0.f, 0.f), bv = rs;
-          const bool n_ok = n < g.N;                                       // N % 4 == 0 is required by the launcher
-          if (n_ok) {
-            rs = *reinterpret_cast<const float4*>(g.rowscale + n);
-            if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + n);
-          }
+          for (int half = 0; half < 2; ++half) {
+            // C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); e>>3 selects rows 16*half..
 #pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int r = it * 8 + (lane >> 3);
-            const float4 v = *reinterpret_cast<const float4*>(eb + r * 144 + c4 * 4);
-            const int m = bm + wm * 64 + tm * 32 + r;
-            if (n_ok && m < g.M && (!(DIAG & 4) || v.x == 12345.f)) {
-              float4 o;
-              o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
-              *reinterpret_cast<float4*>(g.y + (int64_t)m * g.N + n) = o;
+            for (int e8 = 0; e8 < 8; ++e8) {
+              const int r16 = (e8 & 3) + 8 * (e8 >> 2) + 4 * h;
+              *reinterpret_cast<float*>(eb + r16 * 144 + l31 * 4) = acc[tm][tn][half * 8 + e8];
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+              const int r16 = it * 8 + (lane >> 3);
+              const float4 v = *reinterpret_cast<const float4*>(eb + r16 * 144 + c4 * 4);
+              const int m = bm + wm * 64 + tm * 32 + half * 16 + r16;
+              if (n_ok && m < g.M && (!(DIAG & 4) || v.x == 12345.f)) {
+                float4 o;
+                o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
+                *reinterpret_cast<float4*>(g.y + (int64_t)m * g.N + n) = o;
+              }
             }
           }
-        }
+      }
     }
     if (!more) break;
-    __syncthreads();                                    // every wave is done with the epilogue slice of this buffer
     base = (base + T) & 1;
     p = pn; bm = nbm; bn = nbn;
   }
+  if ((DIAG & 16) && tid == 0) {
+    g.dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
+    g.dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+  }
 }
+#undef SPQ_SYNC
 
 // =================================================================================================
 // host side
@@ -653,16 +655,16 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   g.Bhi = (const _Float16*)(wp + P.off_bhi); g.Blo = (const _Float16*)(wp + P.off_blo);
   g.rowinv = x.rowinv; g.rowscale = a->w_rowscale; g.bias = a->bias; g.y = a->y;
   g.M = (int)a->M; g.N = (int)a->N; g.Kp = (int)L.Kp; g.Rp = (int)L.Rp;
-  g.tiles_m = (int)(L.Mp / GM); g.tiles_n = (int)(P.Np / GN);
+  g.tiles_m = (int)(L.Mp / GM); g.tiles_n = (int)(P.Np / GN); g.dbg = nullptr;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_f16x2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * STAGE_BYTES);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %d B): %s", 2 * STAGE_BYTES, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
+                                       GEMM_LDS);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %d B): %s", GEMM_LDS, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
     attr_set = true;
   }
   if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
-  gemm_f16x2_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), 512, 2 * STAGE_BYTES, st>>>(g);
+  gemm_f16x2_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS, st>>>(g);
   if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
   return check_launch("spq_linear_lora_fwd(gemm_f16x2)");
 }

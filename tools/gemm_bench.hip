@@ -13,11 +13,11 @@ using namespace spq;
 
 template <int DIAG>
 float run(const GemmF16Args& g, int iters) {
-  hipFuncSetAttribute((const void*)gemm_f16x2_kernel<DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+  hipFuncSetAttribute((const void*)gemm_f16x2_kernel<DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int i = 0; i < 5; ++i) gemm_f16x2_kernel<DIAG><<<gemm_grid(g.tiles_m * g.tiles_n), 512, 2 * STAGE_BYTES>>>(g);
+  for (int i = 0; i < 5; ++i) gemm_f16x2_kernel<DIAG><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g);
   hipEventRecord(a);
-  for (int i = 0; i < iters; ++i) gemm_f16x2_kernel<DIAG><<<gemm_grid(g.tiles_m * g.tiles_n), 512, 2 * STAGE_BYTES>>>(g);
+  for (int i = 0; i < iters; ++i) gemm_f16x2_kernel<DIAG><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   return ms / iters * 1e3f;
@@ -40,10 +40,22 @@ int main(int argc, char** argv) {
   hipMemset(ri, 0, M * 4); hipMemset(rs, 0, N * 4); hipMemset(bias, 0, N * 4);
   g.rowinv = ri; g.rowscale = rs; g.bias = bias; g.y = y; g.M = M; g.N = N; g.Kp = K; g.Rp = R;
   g.tiles_m = M / GM; g.tiles_n = N / GN;
+  unsigned long long* dbg; hipMalloc(&dbg, 256 * 16); g.dbg = dbg;
+  auto clock_of = [&](auto runner) {
+    runner();
+    std::vector<unsigned long long> h(512); hipMemcpy(h.data(), dbg, 512 * 8, hipMemcpyDeviceToHost);
+    double cyc = 0, rt = 0; for (int i = 0; i < 256; ++i) { cyc += (double)h[2 * i]; rt += (double)h[2 * i + 1]; }
+    return cyc / rt * 100.0;   // MHz: s_memrealtime ticks at 100 MHz
+  };
+  printf("in-kernel clock MHz: full %.0f | mfma-only %.0f | loads-only(no compute) %.0f | loads+mfma %.0f\n",
+         clock_of([&] { run<16>(g, 20); }), clock_of([&] { run<16 + 13>(g, 20); }), clock_of([&] { run<16 + 2>(g, 20); }),
+         clock_of([&] { run<16 + 12>(g, 20); }));
+  printf("2x MFMA per stage: mfma-only %.1f | loads+mfma %.1f us\n", run<32 + 13>(g, 30), run<32 + 12>(g, 30));
+  printf("no barriers at all: mfma-only %.1f | loads-only %.1f | loads+mfma %.1f us\n", run<64 + 13>(g, 30), run<64 + 2 + 4>(g, 30), run<64 + 12>(g, 30));
   const int iters = 50;
   for (int rep = 0; rep < 2; ++rep) {
-    printf("full %.1f | no-loads %.1f | no-compute %.1f | no-stores %.1f | no-loads,no-stores %.1f | mfma-only(no loads/frag reads/stores) %.1f | stores-only %.1f us\n",
-           run<0>(g, iters), run<1>(g, iters), run<2>(g, iters), run<4>(g, iters), run<5>(g, iters), run<13>(g, iters), run<3>(g, iters));
+    printf("full %.1f | no-loads %.1f | no-compute %.1f | no-stores %.1f | no-loads,no-stores %.1f | mfma-only %.1f | stores-only %.1f | loads+mfma(no frag reads, no stores) %.1f us\n",
+           run<0>(g, iters), run<1>(g, iters), run<2>(g, iters), run<4>(g, iters), run<5>(g, iters), run<13>(g, iters), run<3>(g, iters), run<12>(g, iters));
   }
   return 0;
 }
