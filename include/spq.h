@@ -126,7 +126,7 @@ typedef struct spq_fwd_args {
   const void* w_prep;          /* F32: fp32 FQ(W) [N,K];  F16X2: hi/lo limb planes */
   const float* w_rowscale;     /* F16X2: per-row power-of-two descale [N]; else NULL */
   const float* bias;           /* [N] or NULL */
-  const float* a_prep;         /* fp32 FQ(A)^T [r, K] */
+  const float* a_prep;         /* fp32 FQ(A)^T [ceil(r/64)*64, K]; rows >= r are zero (spq_fakequant_transposed into a zeroed buffer) */
   const void* b_prep;          /* F32: fp32 FQ(B)^T [N, r]; F16X2: limb planes */
   float lora_scaling;          /* alpha / rank: multiplies the low-rank partial sum (lora.py:53) */
   /* output + scratch */

@@ -28,6 +28,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int64_t pad_to(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// direct global -> LDS copy, 16 B per lane: LDS destination = wave-uniform base + lane*16, source address per lane
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 constexpr int GM = 256, GN = 128, GK = 64;     // GEMM block tile
 constexpr int XR = 32, XK = 64;                // activation-pass tile: rows per block, k per chunk
 
@@ -177,6 +183,63 @@ struct XPassArgs {
   int x_pc, bits;
 };
 
+// Shared tail of the activation pass: sum the 4 per-wave K-partials of t (fixed order), per-row power-of-two scale,
+// two fp16 limbs.  `red` must hold 4 * XR * RP floats and be free of other use (caller synchronised).
+template <int RT>
+__device__ __forceinline__ void xpass_finish(const XPassArgs& a, const f32x16 (&acc)[RT], float* red, int m0, int tid) {
+  constexpr int RP = RT * 32;
+  const int lane = tid & 63, w = tid >> 6;
+  {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        red[(w * XR + row) * RP + t * 32 + l31] = acc[t][e];
+      }
+  }
+  __syncthreads();
+  // thread -> (row = tid>>3, 8-column segment(s)); 8 consecutive lanes share a row
+  const int row = tid >> 3, seg = tid & 7;
+  constexpr int NSEG = RP / 64;            // 8-col segments per thread
+  float tv[NSEG][8];
+  float rmax = 0.f;
+#pragma unroll
+  for (int sgi = 0; sgi < NSEG; ++sgi) {
+    const int c0 = (sgi * 8 + seg) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float p0 = red[(0 * XR + row) * RP + c0 + j], p1 = red[(1 * XR + row) * RP + c0 + j];
+      const float p2 = red[(2 * XR + row) * RP + c0 + j], p3 = red[(3 * XR + row) * RP + c0 + j];
+      const float v = (p0 + p1) + (p2 + p3);
+      tv[sgi][j] = v;
+      rmax = fmaxf(rmax, fabsf(v));
+    }
+  }
+  rmax = fmaxf(rmax, __shfl_xor(rmax, 1, 64));
+  rmax = fmaxf(rmax, __shfl_xor(rmax, 2, 64));
+  rmax = fmaxf(rmax, __shfl_xor(rmax, 4, 64));
+  const float p = pow2_scale_for(rmax);
+  const int m = m0 + row;
+  if (m < a.M) {
+    if (seg == 0) a.rowinv[m] = 1.0f / p;
+#pragma unroll
+    for (int sgi = 0; sgi < NSEG; ++sgi) {
+      const int c0 = (sgi * 8 + seg) * 8;
+      union { _Float16 h[8]; uint4 u; } hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float ts = tv[sgi][j] * p;                 // exact (power of two)
+        hi.h[j] = (_Float16)ts;
+        lo.h[j] = (_Float16)(ts - (float)hi.h[j]);       // exact residual, rounded once
+      }
+      *reinterpret_cast<uint4*>(a.thi + (int64_t)m * a.Rp + c0) = hi.u;
+      *reinterpret_cast<uint4*>(a.tlo + (int64_t)m * a.Rp + c0) = lo.u;
+    }
+  }
+}
+
 constexpr int XLD = XK + 4;   // fp32 LDS row stride 272 B: slot = 17*row + c (mod 16) -> conflict-free b128 reads
 
 template <int RT>  // RT = Rp / 32 column tiles of t (2 for r<=64, 4 for r<=128)
@@ -289,58 +352,107 @@ __global__ __launch_bounds__(256) void xpass_kernel(XPassArgs a) {
     }
   }
   if (!with_lora) return;
-  // reduce the 4 per-wave partial sums: red[w][row][col]
   __syncthreads();
-  float* red = smem;
-  {
-    const int l31 = lane & 31, h = lane >> 5;
+  xpass_finish<RT>(a, acc, smem, m0, tid);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// Fast activation pass (K % 64 == 0, r <= 64, 16-B aligned rows): the whole 32-row x panel (up to 768 columns =
+// 96 KB) is put in flight at once with direct global->LDS copies, so HBM latency is paid once per workgroup instead of
+// once per 64-column chunk (the generic kernel above is latency-bound at one workgroup per CU).  FQ(A)^T streams
+// through a double buffer one chunk ahead.  LDS images are [chunk][row][64 floats]; the 16-B position p of row r holds
+// source chunk p ^ (r & 15), so the MFMA operand reads (ds_read_b128, row = lane & 31) are conflict-free.
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int XP_CHUNKS = 12;                              // panel = 12 chunks x 64 columns
+constexpr int XP_XS = XP_CHUNKS * XR * 64 * 4;             // 96 KB
+constexpr int XP_AS = 64 * 64 * 4;                         // 16 KB per FQ(A)^T chunk (64 rows of r)
+constexpr int XP_LDS = XP_XS + 2 * XP_AS;                  // 128 KB
+
+__global__ __launch_bounds__(256) void xpass_panel_kernel(XPassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char xsm[];
+  char* xs = xsm;
+  char* as = xsm + XP_XS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * XR;
+  const float qhi = (float)((1 << (a.bits - 1)) - 1), qlo = -qhi;
+  const bool with_lora = a.r > 0;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  f32x16 acc[2];
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-        red[(w * XR + row) * RP + t * 32 + l31] = acc[t][e];
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  // copy pieces: 1 KB = 4 rows x 256 B; lane -> (row = lane>>4, position = lane&15); source chunk = position ^ (row&15)
+  const int prow = lane >> 4, ppos = lane & 15;
+  auto issue_x_chunk = [&](int c_local, int k0) {          // 8 pieces of 4 rows; wave w issues pieces 2w, 2w+1
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (2 * w + i) * 4 + prow;
+      const int m = min(m0 + row, a.M - 1);                // rows past M re-read the last row; their results are dropped
+      glds16(a.x + (int64_t)m * a.K + k0 + ((ppos ^ (row & 15)) << 2), xs + c_local * (XR * 256) + (2 * w + i) * 1024);
+    }
+  };
+  auto issue_a_chunk = [&](int buf, int k0) {              // 16 pieces of 4 rows; wave w issues pieces 4w..4w+3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (4 * w + i) * 4 + prow;
+      glds16(a.aT + (int64_t)row * a.K + k0 + ((ppos ^ (row & 15)) << 2), as + buf * XP_AS + (4 * w + i) * 1024);
+    }
+  };
+
+  int gc = 0;                                              // global chunk counter (FQ(A)^T double buffer parity)
+  for (int p0 = 0; p0 < a.K; p0 += XP_CHUNKS * 64) {
+    const int nch = min(XP_CHUNKS, (a.K - p0) / 64);
+    for (int c = 0; c < nch; ++c) issue_x_chunk(c, p0 + c * 64);
+    if (with_lora) issue_a_chunk(gc & 1, p0);
+    __syncthreads();                                       // vmcnt(0): the panel and the first FQ(A)^T chunk landed
+    for (int c = 0; c < nch; ++c, ++gc) {
+      const int k0 = p0 + c * 64;
+      if (with_lora && k0 + 64 < a.K) issue_a_chunk((gc + 1) & 1, k0 + 64);
+      // ---- integer levels of this chunk: thread -> 2 x (row, 16-B position)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 4, pos = idx & 15;
+        const int k = k0 + ((pos ^ (row & 15)) << 2);
+        const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + row * 256 + pos * 16);
+        float4 sc;
+        if (a.x_pc) sc = *reinterpret_cast<const float4*>(a.sx + k);
+        else { const float s1 = a.sx[0]; sc = make_float4(s1, s1, s1, s1); }
+        union { _Float16 hh[4]; uint2 u; } q;
+        q.hh[0] = (_Float16)minmax_level<true>(v.x, sc.x, 0.f, qlo, qhi);
+        q.hh[1] = (_Float16)minmax_level<true>(v.y, sc.y, 0.f, qlo, qhi);
+        q.hh[2] = (_Float16)minmax_level<true>(v.z, sc.z, 0.f, qlo, qhi);
+        q.hh[3] = (_Float16)minmax_level<true>(v.w, sc.w, 0.f, qlo, qhi);
+        const int m = m0 + row;
+        if (m < a.M) *reinterpret_cast<uint2*>(a.qx + (int64_t)m * a.Kp + k) = q.u;
       }
-  }
-  __syncthreads();
-  // thread -> (row = tid>>3, 8-column segment(s)); 8 consecutive lanes share a row
-  const int row = tid >> 3, seg = tid & 7;
-  constexpr int NSEG = RP / 64;            // 8-col segments per thread
-  float tv[NSEG][8];
-  float rmax = 0.f;
+      // ---- t += x . FQ(A): wave w owns k in [16w, 16w+16) of the chunk, lane half h 8 contiguous k of those
+      if (with_lora) {
+        const int pa = (4 * w + 2 * h);                    // first of the two 16-B source chunks of this lane
+        const char* xrow = xs + c * (XR * 256) + l31 * 256;
+        float av[8];
+        *reinterpret_cast<float4*>(av) = *reinterpret_cast<const float4*>(xrow + ((pa ^ (l31 & 15)) << 4));
+        *reinterpret_cast<float4*>(av + 4) = *reinterpret_cast<const float4*>(xrow + (((pa + 1) ^ (l31 & 15)) << 4));
 #pragma unroll
-  for (int sgi = 0; sgi < NSEG; ++sgi) {
-    const int c0 = (sgi * 8 + seg) * 8;
+        for (int t = 0; t < 2; ++t) {
+          const int rb = t * 32 + l31;
+          const char* brow = as + (gc & 1) * XP_AS + rb * 256;
+          float bv[8];
+          *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(brow + ((pa ^ (rb & 15)) << 4));
+          *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(brow + (((pa + 1) ^ (rb & 15)) << 4));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float p0 = red[(0 * XR + row) * RP + c0 + j], p1 = red[(1 * XR + row) * RP + c0 + j];
-      const float p2 = red[(2 * XR + row) * RP + c0 + j], p3 = red[(3 * XR + row) * RP + c0 + j];
-      const float v = (p0 + p1) + (p2 + p3);
-      tv[sgi][j] = v;
-      rmax = fmaxf(rmax, fabsf(v));
+          for (int s = 0; s < 8; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[t], 0, 0, 0);
+        }
+      }
+      __syncthreads();                                     // next FQ(A)^T chunk landed; this one (and the x chunk) is free
     }
   }
-  rmax = fmaxf(rmax, __shfl_xor(rmax, 1, 64));
-  rmax = fmaxf(rmax, __shfl_xor(rmax, 2, 64));
-  rmax = fmaxf(rmax, __shfl_xor(rmax, 4, 64));
-  const float p = pow2_scale_for(rmax);
-  const int m = m0 + row;
-  if (m < a.M) {
-    if (seg == 0) a.rowinv[m] = 1.0f / p;
-#pragma unroll
-    for (int sgi = 0; sgi < NSEG; ++sgi) {
-      const int c0 = (sgi * 8 + seg) * 8;
-      union { _Float16 h[8]; uint4 u; } hi, lo;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float ts = tv[sgi][j] * p;                 // exact (power of two)
-        hi.h[j] = (_Float16)ts;
-        lo.h[j] = (_Float16)(ts - (float)hi.h[j]);       // exact residual, rounded once
-      }
-      *reinterpret_cast<uint4*>(a.thi + (int64_t)m * a.Rp + c0) = hi.u;
-      *reinterpret_cast<uint4*>(a.tlo + (int64_t)m * a.Rp + c0) = lo.u;
-    }
-  }
+  // K tail columns [K, Kp) of the level matrix are never touched above (K % 64 == 0 => Kp == K)
+  if (!with_lora) return;
+  xpass_finish<2>(a, acc, reinterpret_cast<float*>(xsm), m0, tid);
 }
 
 // =================================================================================================
@@ -367,11 +479,6 @@ constexpr int GEMM_LDS = 2 * STAGE_BYTES + 8 * EPI_WAVE;   // 128 KB + 18 KB
 constexpr int GEMM_THREADS = 512;                  // 8 waves = 4(M) x 2(N), 64x64 outputs each
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
-
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 // DIAG bit mask (tools/gemm_bench only; the library instantiates 0): 1 = no global->LDS copies after the first stage,
 // 2 = no MFMA / fragment reads, 4 = no epilogue stores, 8 = MFMAs on stale registers (no fragment reads),
@@ -644,7 +751,17 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   x.M = (int)a->M; x.K = (int)a->K; x.r = (int)a->r; x.Kp = (int)L.Kp; x.Rp = (int)L.Rp;
   x.x_pc = a->x_per_channel; x.bits = a->bits;
   const unsigned xgrid = (unsigned)((a->M + XR - 1) / XR);
-  if (L.Rp <= 64) xpass_kernel<2><<<xgrid, 256, 0, st>>>(x);
+  const bool panel_ok = (a->K % 64 == 0) && L.Rp <= 64 && aligned16(a->x) && (a->r == 0 || aligned16(a->a_prep)) &&
+                        (!a->x_per_channel || aligned16(a->sx));
+  if (panel_ok) {
+    static bool xattr = false;
+    if (!xattr) {
+      hipError_t e = hipFuncSetAttribute((const void*)xpass_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP_LDS);
+      if (e != hipSuccess) { set_error("hipFuncSetAttribute(xpass LDS %d B): %s", XP_LDS, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
+      xattr = true;
+    }
+    xpass_panel_kernel<<<xgrid, 256, XP_LDS, st>>>(x);
+  } else if (L.Rp <= 64) xpass_kernel<2><<<xgrid, 256, 0, st>>>(x);
   else xpass_kernel<4><<<xgrid, 256, 0, st>>>(x);
   int rc = check_launch("spq_linear_lora_fwd(xpass)");
   if (rc) return rc;

@@ -273,7 +273,7 @@ class SPLinearWithLoRA(nn.Module):
         prep.path, prep.w_rowscale = path, None
         prep.r = lora.rank if use_lora else 0
         with torch.no_grad():
-            prep.a = _fq_transposed(lora.quantize_A, lora.lora_A.detach()) if use_lora else None   # [r,K]
+            prep.a = _fq_transposed(lora.quantize_A, lora.lora_A.detach(), 64) if use_lora else None   # [r->64k, K]
             if path == _lib.PATH_F32:
                 prep.w = qw(W.detach())                                                            # [N,K]
                 prep.b = _fq_transposed(lora.quantize_B, lora.lora_B.detach()) if use_lora else None  # [N,r]
@@ -310,16 +310,20 @@ class SPLinearWithLoRA(nn.Module):
         prep.b = prep.w      # LoRA-B limbs live inside the same buffer
 
 
-def _fq_transposed(q: LearnableFakeQuantize, t: torch.Tensor) -> torch.Tensor:
-    """FQ(t)^T for a 2-D LoRA factor whose scale is per column ([1, cols]) or per tensor."""
+def _fq_transposed(q: LearnableFakeQuantize, t: torch.Tensor, pad_rows_to: int = 1) -> torch.Tensor:
+    """FQ(t)^T for a 2-D LoRA factor whose scale is per column ([1, cols]) or per tensor.  The result may carry
+    zero rows up to a multiple of ``pad_rows_to`` (the activation pass copies FQ(A)^T in 64-row pieces)."""
     _lib.require_gpu(t, "LoRA factor")
     rows, cols = t.shape
+    out_rows = (cols + pad_rows_to - 1) // pad_rows_to * pad_rows_to
     if q.num_bits >= 32:
-        return t.t().contiguous()
+        out = torch.zeros(out_rows, rows, dtype=torch.float32, device=t.device)
+        out[:cols] = t.t()
+        return out
     per_channel = 1 if q.scale.numel() > 1 else 0
     if per_channel and q.scale.numel() != cols:
         raise RuntimeError(f"LoRA scale of shape {tuple(q.scale.shape)} does not fit factor {tuple(t.shape)}")
-    out = torch.empty(cols, rows, dtype=torch.float32, device=t.device)
+    out = torch.zeros(out_rows, rows, dtype=torch.float32, device=t.device)
     tc = t.contiguous()
     with torch.cuda.device(t.device):
         rc = _lib.load().spq_fakequant_transposed(
