@@ -366,12 +366,15 @@ __global__ __launch_bounds__(256) void xpass_kernel(XPassArgs a) {
 constexpr int XP_CHUNKS = 12;                              // panel = 12 chunks x 64 columns
 constexpr int XP_XS = XP_CHUNKS * XR * 64 * 4;             // 96 KB
 constexpr int XP_AS = 64 * 64 * 4;                         // 16 KB per FQ(A)^T chunk (64 rows of r)
-constexpr int XP_LDS = XP_XS + 2 * XP_AS;                  // 128 KB
+constexpr int XP_SX = XP_CHUNKS * 64 * 4;                  // 3 KB: the panel's input scales
+constexpr int XP_NAS = 2;                                  // FQ(A)^T chunk buffers
+constexpr int XP_LDS = XP_XS + XP_NAS * XP_AS + XP_SX;     // 131 KB
 
 __global__ __launch_bounds__(256) void xpass_panel_kernel(XPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) char xsm[];
   char* xs = xsm;
   char* as = xsm + XP_XS;
+  float* sxs = reinterpret_cast<float*>(xsm + XP_XS + XP_NAS * XP_AS);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * XR;
@@ -391,43 +394,72 @@ __global__ __launch_bounds__(256) void xpass_panel_kernel(XPassArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = (2 * w + i) * 4 + prow;
-      const int m = min(m0 + row, a.M - 1);                // rows past M re-read the last row; their results are dropped
+      const int m = min(m0 + row, a.M - 1);                // rows past M re-read the last row (and re-write its results)
       glds16(a.x + (int64_t)m * a.K + k0 + ((ppos ^ (row & 15)) << 2), xs + c_local * (XR * 256) + (2 * w + i) * 1024);
     }
   };
-  auto issue_a_chunk = [&](int buf, int k0) {              // 16 pieces of 4 rows; wave w issues pieces 4w..4w+3
+  // this thread's two (row, 16-B position) slots of a chunk, fixed for the whole kernel
+  int q_row[2], q_pos[2], q_kof[2];
+  int64_t q_out[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (4 * w + i) * 4 + prow;
-      glds16(a.aT + (int64_t)row * a.K + k0 + ((ppos ^ (row & 15)) << 2), as + buf * XP_AS + (4 * w + i) * 1024);
-    }
-  };
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i;
+    q_row[i] = idx >> 4; q_pos[i] = idx & 15;
+    q_kof[i] = (q_pos[i] ^ (q_row[i] & 15)) << 2;
+    q_out[i] = (int64_t)min(m0 + q_row[i], a.M - 1) * a.Kp + q_kof[i];
+  }
 
-  int gc = 0;                                              // global chunk counter (FQ(A)^T double buffer parity)
+  // FQ(A)^T chunk g (global chunk index over all panels) lives in buffer g & 1.  It is staged through registers
+  // (global_load at the top of iteration g-1, ds_write at its bottom): hipcc drains every outstanding LDS-DMA with
+  // vmcnt(0) in front of an LDS read it cannot prove disjoint, which would expose the copy's latency in every chunk.
+  const int total_chunks = a.K / 64;
+  // thread -> 4 x (row = idx>>4, source chunk = idx&15) of a 64-row x 256-B chunk; named registers (an array captured
+  // by a lambda ends up in scratch memory)
+  float4 ra0, ra1, ra2, ra3;
+  ra0 = ra1 = ra2 = ra3 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int a_r = tid >> 4, a_c = tid & 15;               // rows a_r, a_r+16, a_r+32, a_r+48
+  const float* a_src = a.aT + (int64_t)a_r * a.K + (a_c << 2);
+  const int64_t a_step = (int64_t)16 * a.K;
+#define SPQ_LOAD_A(k0)                                                                 \
+  do {                                                                                 \
+    ra0 = *reinterpret_cast<const float4*>(a_src + (k0));                              \
+    ra1 = *reinterpret_cast<const float4*>(a_src + a_step + (k0));                     \
+    ra2 = *reinterpret_cast<const float4*>(a_src + 2 * a_step + (k0));                 \
+    ra3 = *reinterpret_cast<const float4*>(a_src + 3 * a_step + (k0));                 \
+  } while (0)
+  // source chunk c of row r -> position c ^ (r & 15); r & 15 == a_r for all four rows
+  const int a_dst = a_r * 256 + ((a_c ^ a_r) << 4);
+#define SPQ_STORE_A(buf)                                                               \
+  do {                                                                                 \
+    char* d_ = as + (buf) * XP_AS + a_dst;                                             \
+    *reinterpret_cast<float4*>(d_) = ra0;                                              \
+    *reinterpret_cast<float4*>(d_ + 16 * 256) = ra1;                                   \
+    *reinterpret_cast<float4*>(d_ + 32 * 256) = ra2;                                   \
+    *reinterpret_cast<float4*>(d_ + 48 * 256) = ra3;                                   \
+  } while (0)
+  int gc = 0;
+  if (with_lora) SPQ_LOAD_A(0);
   for (int p0 = 0; p0 < a.K; p0 += XP_CHUNKS * 64) {
     const int nch = min(XP_CHUNKS, (a.K - p0) / 64);
     for (int c = 0; c < nch; ++c) issue_x_chunk(c, p0 + c * 64);
-    if (with_lora) issue_a_chunk(gc & 1, p0);
-    __syncthreads();                                       // vmcnt(0): the panel and the first FQ(A)^T chunk landed
+    for (int k = tid; k < nch * 64; k += 256) sxs[k] = a.x_pc ? a.sx[p0 + k] : a.sx[0];
+    if (with_lora && p0 == 0) SPQ_STORE_A(0);
+    __syncthreads();                                       // vmcnt(0): the panel landed; FQ(A)^T chunk gc is in LDS
     for (int c = 0; c < nch; ++c, ++gc) {
       const int k0 = p0 + c * 64;
-      if (with_lora && k0 + 64 < a.K) issue_a_chunk((gc + 1) & 1, k0 + 64);
-      // ---- integer levels of this chunk: thread -> 2 x (row, 16-B position)
+      const bool next_a = with_lora && gc + 1 < total_chunks;
+      if (next_a) SPQ_LOAD_A((gc + 1) * 64);                // lands under this chunk's work
+      // ---- integer levels of this chunk
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int idx = tid + 256 * i, row = idx >> 4, pos = idx & 15;
-        const int k = k0 + ((pos ^ (row & 15)) << 2);
-        const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + row * 256 + pos * 16);
-        float4 sc;
-        if (a.x_pc) sc = *reinterpret_cast<const float4*>(a.sx + k);
-        else { const float s1 = a.sx[0]; sc = make_float4(s1, s1, s1, s1); }
+        const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + q_row[i] * 256 + q_pos[i] * 16);
+        const float4 sc = *reinterpret_cast<const float4*>(sxs + c * 64 + q_kof[i]);
         union { _Float16 hh[4]; uint2 u; } q;
         q.hh[0] = (_Float16)minmax_level<true>(v.x, sc.x, 0.f, qlo, qhi);
         q.hh[1] = (_Float16)minmax_level<true>(v.y, sc.y, 0.f, qlo, qhi);
         q.hh[2] = (_Float16)minmax_level<true>(v.z, sc.z, 0.f, qlo, qhi);
         q.hh[3] = (_Float16)minmax_level<true>(v.w, sc.w, 0.f, qlo, qhi);
-        const int m = m0 + row;
-        if (m < a.M) *reinterpret_cast<uint2*>(a.qx + (int64_t)m * a.Kp + k) = q.u;
+        *reinterpret_cast<uint2*>(a.qx + q_out[i] + k0) = q.u;
       }
       // ---- t += x . FQ(A): wave w owns k in [16w, 16w+16) of the chunk, lane half h 8 contiguous k of those
       if (with_lora) {
@@ -446,11 +478,16 @@ __global__ __launch_bounds__(256) void xpass_panel_kernel(XPassArgs a) {
 #pragma unroll
           for (int s = 0; s < 8; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[t], 0, 0, 0);
         }
+        if (next_a) SPQ_STORE_A((gc + 1) & 1);             // the other buffer: every wave left it at the last barrier
       }
-      __syncthreads();                                     // next FQ(A)^T chunk landed; this one (and the x chunk) is free
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS writes are done (the level stores may stay in flight)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
+    __syncthreads();                                       // panel images are free for the next panel
   }
-  // K tail columns [K, Kp) of the level matrix are never touched above (K % 64 == 0 => Kp == K)
+#undef SPQ_LOAD_A
+#undef SPQ_STORE_A
   if (!with_lora) return;
   xpass_finish<2>(a, acc, reinterpret_cast<float*>(xsm), m0, tid);
 }
@@ -625,6 +662,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_kernel(GemmF16Args
     const bool more = pn < nwg;
     int nbm = 0, nbn = 0;
     if (more) tile_of(pn, nbm, nbn);
+    // epilogue operands of this tile, fetched now so that nothing has to be waited for at the end
+    float4 ep_rs[2], ep_bv[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
+      ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
+      if (n < g.N) {
+        ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);
+        if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
+      }
+    }
 
     // LoRA segment first, so that its per-row scale applies to it alone
     for (int t = 0; t < nl; t += 2) {
@@ -649,18 +697,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_kernel(GemmF16Args
 
     // ---- epilogue: y = acc * 2^-e[n] + bias[n].  Each wave transposes 16 rows x 32 cols at a time through its
     // private LDS slice (row stride 144 B) and stores 16 B per lane: 8 rows x 128 B per instruction, whole lines.
+    // Interior tiles take a branch-free path (a lane-divergent guard makes hipcc wait vmcnt(0) after every store).
     {
       char* eb = smem + 2 * STAGE_BYTES + w * EPI_WAVE;
       const int c4 = (lane & 7) * 4;                     // 8 lanes x 16 B per 128-B row
+      const bool interior = (bm + GM <= g.M) && (bn + GN <= g.N);
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
         const int n = bn + wn * 64 + tn * 32 + c4;
-        float4 rs = make_float4(0.f, 0.f, 0.f, 0.f), bv = rs;
         const bool n_ok = n < g.N;                       // N % 4 == 0 is required by the launcher
-        if (n_ok) {
-          rs = *reinterpret_cast<const float4*>(g.rowscale + n);
-          if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + n);
-        }
+        const float4 rs = ep_rs[tn], bv = ep_bv[tn];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -676,11 +722,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_kernel(GemmF16Args
               const int r16 = it * 8 + (lane >> 3);
               const float4 v = *reinterpret_cast<const float4*>(eb + r16 * 144 + c4 * 4);
               const int m = bm + wm * 64 + tm * 32 + half * 16 + r16;
-              if (n_ok && m < g.M && (!(DIAG & 4) || v.x == 12345.f)) {
-                float4 o;
-                o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
-                *reinterpret_cast<float4*>(g.y + (int64_t)m * g.N + n) = o;
-              }
+              float4 o;
+              o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
+              float* dst = g.y + (int64_t)m * g.N + n;
+              if (DIAG & 4) { if (v.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }
+              else if (interior) *reinterpret_cast<float4*>(dst) = o;
+              else if (n_ok && m < g.M) *reinterpret_cast<float4*>(dst) = o;
             }
           }
       }
