@@ -102,9 +102,11 @@ __device__ __forceinline__ float fq_dispatch(float v, float s, float z, int bits
   return sym ? fq_value<SPQ_LOG, true>(v, s, z, bits) : fq_value<SPQ_LOG, false>(v, s, z, bits);
 }
 
-__device__ __forceinline__ void split2(double v, _Float16& hi, _Float16& lo) {
-  hi = (_Float16)v;                     // round-to-nearest fp16
-  lo = (_Float16)(v - (double)hi);      // exact residual in fp64, rounded once
+// v = hi + lo up to 2^-22 |v|: hi = RN_f16(v), lo = RN_f16(v - hi); the residual is exact in fp32 (hi carries 11 of
+// v's 24 significant bits).  All in fp32: gfx950 has no f64->f16 conversion (clang expands one to ~30 instructions).
+__device__ __forceinline__ void split2(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
 }
 
 __global__ __launch_bounds__(256) void prep_f16x2_kernel(PrepArgs a) {
@@ -127,8 +129,7 @@ __global__ __launch_bounds__(256) void prep_f16x2_kernel(PrepArgs a) {
   float vmax = 0.f;
   for (int k = tid; k < a.K; k += 256) {
     const float wq = fq_dispatch(a.W[(int64_t)n * a.K + k], swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
-    const double wp = (double)wq * (double)a.sx[a.x_pc ? k : 0];
-    vmax = fmaxf(vmax, fabsf((float)wp));
+    vmax = fmaxf(vmax, fabsf(wq * a.sx[a.x_pc ? k : 0]));
   }
   if (a.B) {
     const float sbn = a.sb[a.b_pc ? n : 0], zbn = a.zb[a.b_pc ? n : 0];
@@ -142,18 +143,18 @@ __global__ __launch_bounds__(256) void prep_f16x2_kernel(PrepArgs a) {
   __syncthreads();
   if (tid == 0) {
     const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    const float p = pow2_scale_for(m * 1.0000002f);   // margin: the fp32 max may sit 1 ulp under the fp64 product
+    const float p = pow2_scale_for(m);
     s_scale = p;
     a.rowscale[n] = 1.0f / p;                          // exact: p is a power of two
   }
   __syncthreads();
-  const double p = (double)s_scale;
+  const float p = s_scale;
   // pass 2: limbs (recomputed rather than staged: the row is tiny and L2-resident)
   for (int k = tid; k < a.Kp; k += 256) {
     _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
     if (k < a.K) {
       const float wq = fq_dispatch(a.W[(int64_t)n * a.K + k], swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
-      split2((double)wq * (double)a.sx[a.x_pc ? k : 0] * p, h, l);
+      split2((wq * a.sx[a.x_pc ? k : 0]) * p, h, l);            // W' = fl32(FQ(W) * sx), exactly scaled by 2^e
     }
     whi[k] = h; wlo[k] = l;
   }
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void prep_f16x2_kernel(PrepArgs a) {
       _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
       if (a.B && j < a.r) {
         const float bq = fq_dispatch(a.B[(int64_t)j * a.N + n], sbn, zbn, a.b_bits, a.b_qtype, a.b_sym);
-        split2((double)(bq * a.scaling) * p, h, l);    // (t@Bq)*scaling == t@(Bq*scaling) up to one fp32 rounding
+        split2((bq * a.scaling) * p, h, l);            // (t@Bq)*scaling == t@(Bq*scaling) up to one fp32 rounding
       }
       bhi[j] = h; blo[j] = l;
     }
@@ -182,6 +183,93 @@ struct XPassArgs {
   int M, K, r, Kp, Rp;
   int x_pc, bits;
 };
+
+// One WAVE per output row (4 rows per workgroup): the row's FQ(W) values stay in registers between the max pass and
+// the limb pass, reductions are 64-lane shuffles, loads are 16 B per lane and stores 8 B per lane.  Needs K % 4 == 0,
+// K <= 4096, 16-B aligned W / sx.
+constexpr int PREP_MAXI = 16;
+__global__ __launch_bounds__(256) void prep_f16x2_wave_kernel(PrepArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  _Float16* whi = a.Whi + (int64_t)n * a.Kp;
+  _Float16* wlo = a.Wlo + (int64_t)n * a.Kp;
+  _Float16* bhi = a.Bhi ? a.Bhi + (int64_t)n * a.Rp : nullptr;
+  _Float16* blo = a.Blo ? a.Blo + (int64_t)n * a.Rp : nullptr;
+  const int kp4 = a.Kp >> 2, k4n = a.K >> 2;
+  if (n >= a.N) {                       // padding rows: zeros
+    for (int k4 = lane; k4 < kp4; k4 += 64) {
+      *reinterpret_cast<uint2*>(whi + 4 * k4) = make_uint2(0, 0);
+      *reinterpret_cast<uint2*>(wlo + 4 * k4) = make_uint2(0, 0);
+    }
+    if (bhi) for (int j = lane; j < a.Rp; j += 64) { bhi[j] = (_Float16)0.f; blo[j] = (_Float16)0.f; }
+    if (lane == 0) a.rowscale[n] = 1.f;
+    return;
+  }
+  const float swn = a.sw[a.w_pc ? n : 0], zwn = a.zw[a.w_pc ? n : 0];
+  const float4* Wrow = reinterpret_cast<const float4*>(a.W + (int64_t)n * a.K);
+  float4 wq[PREP_MAXI];
+  float vmax = 0.f;
+#pragma unroll
+  for (int i = 0; i < PREP_MAXI; ++i) {
+    const int k4 = lane + 64 * i;
+    if (k4 < k4n) {
+      const float4 v = Wrow[k4];
+      float4 q;
+      q.x = fq_dispatch(v.x, swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
+      q.y = fq_dispatch(v.y, swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
+      q.z = fq_dispatch(v.z, swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
+      q.w = fq_dispatch(v.w, swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
+      float4 sc;
+      if (a.x_pc) sc = *reinterpret_cast<const float4*>(a.sx + 4 * k4);
+      else { const float s1 = a.sx[0]; sc = make_float4(s1, s1, s1, s1); }
+      q.x *= sc.x; q.y *= sc.y; q.z *= sc.z; q.w *= sc.w;    // W' = fl32(FQ(W) * sx)
+      wq[i] = q;
+      vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w))));
+    }
+  }
+  float bq[2] = {0.f, 0.f};
+  if (a.B) {
+    const float sbn = a.sb[a.b_pc ? n : 0], zbn = a.zb[a.b_pc ? n : 0];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = lane + 64 * i;
+      if (j < a.r) {
+        bq[i] = fq_dispatch(a.B[(int64_t)j * a.N + n], sbn, zbn, a.b_bits, a.b_qtype, a.b_sym) * a.scaling;
+        vmax = fmaxf(vmax, fabsf(bq[i]));
+      }
+    }
+  }
+  vmax = wave_max(vmax);
+  const float p = pow2_scale_for(vmax);
+  if (lane == 0) a.rowscale[n] = 1.0f / p;               // exact: p is a power of two
+#pragma unroll
+  for (int i = 0; i < PREP_MAXI; ++i) {
+    const int k4 = lane + 64 * i;
+    if (k4 < kp4) {
+      union { _Float16 h[4]; uint2 u; } hi, lo;
+      hi.u = make_uint2(0, 0); lo.u = make_uint2(0, 0);
+      if (k4 < k4n) {
+        split2(wq[i].x * p, hi.h[0], lo.h[0]);
+        split2(wq[i].y * p, hi.h[1], lo.h[1]);
+        split2(wq[i].z * p, hi.h[2], lo.h[2]);
+        split2(wq[i].w * p, hi.h[3], lo.h[3]);
+      }
+      *reinterpret_cast<uint2*>(whi + 4 * k4) = hi.u;
+      *reinterpret_cast<uint2*>(wlo + 4 * k4) = lo.u;
+    }
+  }
+  if (bhi) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = lane + 64 * i;
+      if (j < a.Rp) {
+        _Float16 hh = (_Float16)0.f, ll = (_Float16)0.f;
+        if (a.B && j < a.r) split2(bq[i] * p, hh, ll);
+        bhi[j] = hh; blo[j] = ll;
+      }
+    }
+  }
+}
 
 // Shared tail of the activation pass: sum the 4 per-wave K-partials of t (fixed order), per-row power-of-two scale,
 // two fp16 limbs.  `red` must hold 4 * XR * RP floats and be free of other use (caller synchronised).
@@ -864,6 +952,8 @@ extern "C" int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const flo
   a.w_pc = w_per_channel; a.w_bits = w_bits; a.w_qtype = w_qtype; a.w_sym = w_symmetric;
   a.b_pc = b_per_channel; a.b_bits = b_bits; a.b_qtype = b_qtype; a.b_sym = b_symmetric;
   a.x_pc = x_per_channel; a.scaling = scaling;
-  prep_f16x2_kernel<<<(unsigned)P.Np, 256, 0, (hipStream_t)stream>>>(a);
+  const bool wave_ok = (K % 4 == 0) && K <= 4 * 64 * PREP_MAXI && aligned16(W) && (!x_per_channel || aligned16(sx)) && r <= 128;
+  if (wave_ok) prep_f16x2_wave_kernel<<<(unsigned)(P.Np / 4), 256, 0, (hipStream_t)stream>>>(a);
+  else prep_f16x2_kernel<<<(unsigned)P.Np, 256, 0, (hipStream_t)stream>>>(a);
   return check_launch("spq_prepare_f16x2");
 }
