@@ -271,9 +271,10 @@ __global__ __launch_bounds__(256) void prep_f16x2_wave_kernel(PrepArgs a) {
   }
 }
 
-// Shared tail of the activation pass: sum the 4 per-wave K-partials of t (fixed order), per-row power-of-two scale,
-// two fp16 limbs.  `red` must hold 4 * XR * RP floats and be free of other use (caller synchronised).
-template <int RT>
+// Shared tail of the activation pass: sum the NW per-wave K-partials of t (fixed order), per-row power-of-two scale,
+// two fp16 limbs.  `red` must hold NW * XR * RP floats and be free of other use (caller synchronised).  All threads
+// of the workgroup enter; threads >= 256 only contribute their partial.
+template <int RT, int NW>
 __device__ __forceinline__ void xpass_finish(const XPassArgs& a, const f32x16 (&acc)[RT], float* red, int m0, int tid) {
   constexpr int RP = RT * 32;
   const int lane = tid & 63, w = tid >> 6;
@@ -288,6 +289,7 @@ __device__ __forceinline__ void xpass_finish(const XPassArgs& a, const f32x16 (&
       }
   }
   __syncthreads();
+  if (tid >= 256) return;
   // thread -> (row = tid>>3, 8-column segment(s)); 8 consecutive lanes share a row
   const int row = tid >> 3, seg = tid & 7;
   constexpr int NSEG = RP / 64;            // 8-col segments per thread
@@ -298,11 +300,15 @@ __device__ __forceinline__ void xpass_finish(const XPassArgs& a, const f32x16 (&
     const int c0 = (sgi * 8 + seg) * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float p0 = red[(0 * XR + row) * RP + c0 + j], p1 = red[(1 * XR + row) * RP + c0 + j];
-      const float p2 = red[(2 * XR + row) * RP + c0 + j], p3 = red[(3 * XR + row) * RP + c0 + j];
-      const float v = (p0 + p1) + (p2 + p3);
-      tv[sgi][j] = v;
-      rmax = fmaxf(rmax, fabsf(v));
+      float part[NW];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) part[q] = red[(q * XR + row) * RP + c0 + j];
+#pragma unroll
+      for (int st = 1; st < NW; st *= 2)                  // fixed pairwise tree: ((p0+p1)+(p2+p3))+...
+#pragma unroll
+        for (int q = 0; q + st < NW; q += 2 * st) part[q] = part[q] + part[q + st];
+      tv[sgi][j] = part[0];
+      rmax = fmaxf(rmax, fabsf(part[0]));
     }
   }
   rmax = fmaxf(rmax, __shfl_xor(rmax, 1, 64));
@@ -317,11 +323,7 @@ __device__ __forceinline__ void xpass_finish(const XPassArgs& a, const f32x16 (&
       const int c0 = (sgi * 8 + seg) * 8;
       union { _Float16 h[8]; uint4 u; } hi, lo;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float ts = tv[sgi][j] * p;                 // exact (power of two)
-        hi.h[j] = (_Float16)ts;
-        lo.h[j] = (_Float16)(ts - (float)hi.h[j]);       // exact residual, rounded once
-      }
+      for (int j = 0; j < 8; ++j) split2(tv[sgi][j] * p, hi.h[j], lo.h[j]);   // * p exact (power of two)
       *reinterpret_cast<uint4*>(a.thi + (int64_t)m * a.Rp + c0) = hi.u;
       *reinterpret_cast<uint4*>(a.tlo + (int64_t)m * a.Rp + c0) = lo.u;
     }
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(256) void xpass_kernel(XPassArgs a) {
   }
   if (!with_lora) return;
   __syncthreads();
-  xpass_finish<RT>(a, acc, smem, m0, tid);
+  xpass_finish<RT, 4>(a, acc, smem, m0, tid);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -458,13 +460,13 @@ constexpr int XP_SX = XP_CHUNKS * 64 * 4;                  // 3 KB: the panel's 
 constexpr int XP_NAS = 2;                                  // FQ(A)^T chunk buffers
 constexpr int XP_LDS = XP_XS + XP_NAS * XP_AS + XP_SX;     // 131 KB
 
-__global__ __launch_bounds__(256) void xpass_panel_kernel(XPassArgs a) {
+__global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) char xsm[];
   char* xs = xsm;
   char* as = xsm + XP_XS;
   float* sxs = reinterpret_cast<float*>(xsm + XP_XS + XP_NAS * XP_AS);
   const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // 8 waves: two per SIMD, so one's VALU runs under the other's MFMAs
   const int m0 = blockIdx.x * XR;
   const float qhi = (float)((1 << (a.bits - 1)) - 1), qlo = -qhi;
   const bool with_lora = a.r > 0;
@@ -476,95 +478,73 @@ __global__ __launch_bounds__(256) void xpass_panel_kernel(XPassArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-  // copy pieces: 1 KB = 4 rows x 256 B; lane -> (row = lane>>4, position = lane&15); source chunk = position ^ (row&15)
-  const int prow = lane >> 4, ppos = lane & 15;
-  auto issue_x_chunk = [&](int c_local, int k0) {          // 8 pieces of 4 rows; wave w issues pieces 2w, 2w+1
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = (2 * w + i) * 4 + prow;
-      const int m = min(m0 + row, a.M - 1);                // rows past M re-read the last row (and re-write its results)
-      glds16(a.x + (int64_t)m * a.K + k0 + ((ppos ^ (row & 15)) << 2), xs + c_local * (XR * 256) + (2 * w + i) * 1024);
-    }
-  };
-  // this thread's two (row, 16-B position) slots of a chunk, fixed for the whole kernel
-  int q_row[2], q_pos[2], q_kof[2];
-  int64_t q_out[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = tid + 256 * i;
-    q_row[i] = idx >> 4; q_pos[i] = idx & 15;
-    q_kof[i] = (q_pos[i] ^ (q_row[i] & 15)) << 2;
-    q_out[i] = (int64_t)min(m0 + q_row[i], a.M - 1) * a.Kp + q_kof[i];
-  }
+  // x copy pieces: 1 KB = 4 rows x 256 B; lane -> (row = lane>>4, position = lane&15); source chunk = position ^ (row&15)
+  // a 64-column chunk of the 32-row panel is 8 pieces: wave w issues piece w
+  const int prow = w * 4 + (lane >> 4), ppos = lane & 15;
+  const float* x_src = a.x + (int64_t)min(m0 + prow, a.M - 1) * a.K + ((ppos ^ (prow & 15)) << 2);   // rows past M re-read row M-1
+  // this thread's (row, 16-B position) slot of a chunk for the level pass, fixed for the whole kernel
+  const int q_row = tid >> 4, q_pos = tid & 15;
+  const int q_kof = (q_pos ^ (q_row & 15)) << 2;
+  _Float16* q_dst = a.qx + (int64_t)min(m0 + q_row, a.M - 1) * a.Kp + q_kof;
 
   // FQ(A)^T chunk g (global chunk index over all panels) lives in buffer g & 1.  It is staged through registers
   // (global_load at the top of iteration g-1, ds_write at its bottom): hipcc drains every outstanding LDS-DMA with
   // vmcnt(0) in front of an LDS read it cannot prove disjoint, which would expose the copy's latency in every chunk.
+  // thread -> 2 x (row = tid>>4 (+32), source chunk = tid&15) of a 64-row x 256-B chunk
   const int total_chunks = a.K / 64;
-  // thread -> 4 x (row = idx>>4, source chunk = idx&15) of a 64-row x 256-B chunk; named registers (an array captured
-  // by a lambda ends up in scratch memory)
-  float4 ra0, ra1, ra2, ra3;
-  ra0 = ra1 = ra2 = ra3 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int a_r = tid >> 4, a_c = tid & 15;               // rows a_r, a_r+16, a_r+32, a_r+48
+  float4 ra0, ra1;
+  ra0 = ra1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int a_r = tid >> 4, a_c = tid & 15;
   const float* a_src = a.aT + (int64_t)a_r * a.K + (a_c << 2);
-  const int64_t a_step = (int64_t)16 * a.K;
+  const int64_t a_step = (int64_t)32 * a.K;
+  const int a_dst = a_r * 256 + ((a_c ^ (a_r & 15)) << 4);       // (a_r + 32) & 15 == a_r & 15
 #define SPQ_LOAD_A(k0)                                                                 \
   do {                                                                                 \
     ra0 = *reinterpret_cast<const float4*>(a_src + (k0));                              \
     ra1 = *reinterpret_cast<const float4*>(a_src + a_step + (k0));                     \
-    ra2 = *reinterpret_cast<const float4*>(a_src + 2 * a_step + (k0));                 \
-    ra3 = *reinterpret_cast<const float4*>(a_src + 3 * a_step + (k0));                 \
   } while (0)
-  // source chunk c of row r -> position c ^ (r & 15); r & 15 == a_r for all four rows
-  const int a_dst = a_r * 256 + ((a_c ^ a_r) << 4);
 #define SPQ_STORE_A(buf)                                                               \
   do {                                                                                 \
     char* d_ = as + (buf) * XP_AS + a_dst;                                             \
     *reinterpret_cast<float4*>(d_) = ra0;                                              \
-    *reinterpret_cast<float4*>(d_ + 16 * 256) = ra1;                                   \
-    *reinterpret_cast<float4*>(d_ + 32 * 256) = ra2;                                   \
-    *reinterpret_cast<float4*>(d_ + 48 * 256) = ra3;                                   \
+    *reinterpret_cast<float4*>(d_ + 32 * 256) = ra1;                                   \
   } while (0)
+
   int gc = 0;
   if (with_lora) SPQ_LOAD_A(0);
   for (int p0 = 0; p0 < a.K; p0 += XP_CHUNKS * 64) {
     const int nch = min(XP_CHUNKS, (a.K - p0) / 64);
-    for (int c = 0; c < nch; ++c) issue_x_chunk(c, p0 + c * 64);
-    for (int k = tid; k < nch * 64; k += 256) sxs[k] = a.x_pc ? a.sx[p0 + k] : a.sx[0];
+    for (int c = 0; c < nch; ++c) glds16(x_src + p0 + c * 64, xs + c * (XR * 256) + w * 1024);
+    for (int k = tid; k < nch * 64; k += 512) sxs[k] = a.x_pc ? a.sx[p0 + k] : a.sx[0];
     if (with_lora && p0 == 0) SPQ_STORE_A(0);
     __syncthreads();                                       // vmcnt(0): the panel landed; FQ(A)^T chunk gc is in LDS
     for (int c = 0; c < nch; ++c, ++gc) {
       const int k0 = p0 + c * 64;
       const bool next_a = with_lora && gc + 1 < total_chunks;
       if (next_a) SPQ_LOAD_A((gc + 1) * 64);                // lands under this chunk's work
-      // ---- integer levels of this chunk
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + q_row[i] * 256 + q_pos[i] * 16);
-        const float4 sc = *reinterpret_cast<const float4*>(sxs + c * 64 + q_kof[i]);
+      // ---- integer levels of this chunk: one float4 per thread
+      {
+        const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + q_row * 256 + q_pos * 16);
+        const float4 sc = *reinterpret_cast<const float4*>(sxs + c * 64 + q_kof);
         union { _Float16 hh[4]; uint2 u; } q;
         q.hh[0] = (_Float16)minmax_level<true>(v.x, sc.x, 0.f, qlo, qhi);
         q.hh[1] = (_Float16)minmax_level<true>(v.y, sc.y, 0.f, qlo, qhi);
         q.hh[2] = (_Float16)minmax_level<true>(v.z, sc.z, 0.f, qlo, qhi);
         q.hh[3] = (_Float16)minmax_level<true>(v.w, sc.w, 0.f, qlo, qhi);
-        *reinterpret_cast<uint2*>(a.qx + q_out[i] + k0) = q.u;
+        *reinterpret_cast<uint2*>(q_dst + k0) = q.u;
       }
-      // ---- t += x . FQ(A): wave w owns k in [16w, 16w+16) of the chunk, lane half h 8 contiguous k of those
+      // ---- t += x . FQ(A): wave w owns k in [8w, 8w+8) of the chunk, lane half h the 4 contiguous k 8w+4h..+3
       if (with_lora) {
-        const int pa = (4 * w + 2 * h);                    // first of the two 16-B source chunks of this lane
-        const char* xrow = xs + c * (XR * 256) + l31 * 256;
-        float av[8];
-        *reinterpret_cast<float4*>(av) = *reinterpret_cast<const float4*>(xrow + ((pa ^ (l31 & 15)) << 4));
-        *reinterpret_cast<float4*>(av + 4) = *reinterpret_cast<const float4*>(xrow + (((pa + 1) ^ (l31 & 15)) << 4));
+        const int pa = 2 * w + h;                          // 16-B source chunk of this lane
+        const float4 av = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + l31 * 256 + ((pa ^ (l31 & 15)) << 4));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int rb = t * 32 + l31;
-          const char* brow = as + (gc & 1) * XP_AS + rb * 256;
-          float bv[8];
-          *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(brow + ((pa ^ (rb & 15)) << 4));
-          *reinterpret_cast<float4*>(bv + 4) = *reinterpret_cast<const float4*>(brow + (((pa + 1) ^ (rb & 15)) << 4));
-#pragma unroll
-          for (int s = 0; s < 8; ++s) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[t], 0, 0, 0);
+          const float4 bv = *reinterpret_cast<const float4*>(as + (gc & 1) * XP_AS + rb * 256 + ((pa ^ (rb & 15)) << 4));
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
         }
         if (next_a) SPQ_STORE_A((gc + 1) & 1);             // the other buffer: every wave left it at the last barrier
       }
@@ -577,7 +557,7 @@ __global__ __launch_bounds__(256) void xpass_panel_kernel(XPassArgs a) {
 #undef SPQ_LOAD_A
 #undef SPQ_STORE_A
   if (!with_lora) return;
-  xpass_finish<2>(a, acc, reinterpret_cast<float*>(xsm), m0, tid);
+  xpass_finish<2, 8>(a, acc, reinterpret_cast<float*>(xsm), m0, tid);
 }
 
 // =================================================================================================
@@ -895,7 +875,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(xpass LDS %d B): %s", XP_LDS, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
       xattr = true;
     }
-    xpass_panel_kernel<<<xgrid, 256, XP_LDS, st>>>(x);
+    xpass_panel_kernel<<<xgrid, 512, XP_LDS, st>>>(x);
   } else if (L.Rp <= 64) xpass_kernel<2><<<xgrid, 256, 0, st>>>(x);
   else xpass_kernel<4><<<xgrid, 256, 0, st>>>(x);
   int rc = check_launch("spq_linear_lora_fwd(xpass)");
