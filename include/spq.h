@@ -147,15 +147,18 @@ int spq_linear_lora_fwd(const spq_fwd_args* args, spq_stream_t stream);
  * the weight and LoRA quantizers may be of any type).  Replaces the per-call FQ(W) of lora.py:142 and FQ(B) of
  * lora.py:50, and folds the input scale sx[k] (quantization.py scale of quantizers_input) into the weight:
  *   W'[n,k] = FQ(W)[n,k] * sx[k],  B'[n,j] = scaling * FQ(B)[j,n];  both * 2^e[n], split into two fp16 limbs.
- * W [N,K]; B [r,N] (nullable when r = 0); quantizer params have N entries (per_channel) or 1.
+ * W [N,K]; B [r,N], A [K,r] (nullable when r = 0); B's quantizer params have N entries (per_channel) or 1, A's r or 1.
+ * a_prep (out): FQ(A)^T in rows 0..r-1 of a caller-zeroed [ceil(r/64)*64, K] fp32 buffer (lora.py:49), same launch.
  * w_prep: spq_prep_f16x2_bytes() bytes, 16-B aligned.  w_rowscale: ceil(N/128)*128 floats (2^-e[n]).
  * ------------------------------------------------------------------------------------------------- */
 size_t spq_prep_f16x2_bytes(int64_t N, int64_t K, int64_t r);
 int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const float* sw, const float* zw,
                       int w_per_channel, int w_bits, int w_qtype, int w_symmetric, const float* B, int64_t r,
                       const float* sb, const float* zb, int b_per_channel, int b_bits, int b_qtype,
-                      int b_symmetric, float scaling, const float* sx, int x_per_channel, void* w_prep,
-                      size_t w_prep_bytes, float* w_rowscale, spq_stream_t stream);
+                      int b_symmetric, float scaling, const float* A, const float* sa, const float* za,
+                      int a_per_channel, int a_bits, int a_qtype, int a_symmetric, const float* sx,
+                      int x_per_channel, void* w_prep, size_t w_prep_bytes, float* w_rowscale, float* a_prep,
+                      spq_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -49,8 +49,10 @@ SIGNATURES = {
     "spq_fwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int]),
     "spq_linear_lora_fwd": (_int, [C.POINTER(FwdArgs), _p]),
     "spq_prep_f16x2_bytes": (_sz, [_i64, _i64, _i64]),
-    "spq_prepare_f16x2": (_int, [_p, _i64, _i64, _p, _p, _int, _int, _int, _int, _p, _i64, _p, _p, _int, _int, _int,
-                                 _int, _f, _p, _int, _p, _sz, _p, _p]),
+    "spq_prepare_f16x2": (_int, [_p, _i64, _i64, _p, _p, _int, _int, _int, _int,          # W
+                                 _p, _i64, _p, _p, _int, _int, _int, _int, _f,            # B
+                                 _p, _p, _p, _int, _int, _int, _int,                      # A
+                                 _p, _int, _p, _sz, _p, _p, _p]),                         # sx, outputs, stream
 }
 
 

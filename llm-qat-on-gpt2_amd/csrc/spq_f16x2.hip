@@ -81,6 +81,10 @@ struct PrepArgs {
   int b_pc, b_bits, b_qtype, b_sym;
   int x_pc;
   float scaling;
+  // fused job: aT[c, k] = FQ(A)[k, c] for A [K, r] (32x32 tiles in the workgroups after the row workgroups)
+  const float* A; const float* sa; const float* za; float* aT;
+  int a_pc, a_bits, a_qtype, a_sym;
+  int row_blocks;
 };
 
 template <int QT, bool SYM>
@@ -109,7 +113,32 @@ __device__ __forceinline__ void split2(float v, _Float16& hi, _Float16& lo) {
   lo = (_Float16)(v - (float)hi);
 }
 
+// aT[c, k] = FQ(A)[k, c]: one 32x32 tile per workgroup of 256 threads (lora.py:49: FQ(A) is recomputed every forward)
+__device__ __forceinline__ void fq_transpose_tile(const PrepArgs& a, int tile) {
+  __shared__ float tl[32][33];
+  const int tiles_c = (a.r + 31) / 32;
+  const int tc = tile % tiles_c, tk = tile / tiles_c;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = tc * 32 + tx;
+  for (int j = ty; j < 32; j += 8) {
+    const int k = tk * 32 + j;
+    float o = 0.f;
+    if (k < a.K && c < a.r) {
+      const int ch = a.a_pc ? c : 0;
+      o = fq_dispatch(a.A[(int64_t)k * a.r + c], a.sa[ch], a.za[ch], a.a_bits, a.a_qtype, a.a_sym);
+    }
+    tl[j][tx] = o;
+  }
+  __syncthreads();
+  const int k = tk * 32 + tx;
+  for (int j = ty; j < 32; j += 8) {
+    const int cc = tc * 32 + j;
+    if (k < a.K && cc < a.r) a.aT[(int64_t)cc * a.K + k] = tl[tx][j];
+  }
+}
+
 __global__ __launch_bounds__(256) void prep_f16x2_kernel(PrepArgs a) {
+  if ((int)blockIdx.x >= a.row_blocks) { fq_transpose_tile(a, blockIdx.x - a.row_blocks); return; }
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
   __shared__ float s_red[4];
@@ -189,6 +218,7 @@ struct XPassArgs {
 // K <= 4096, 16-B aligned W / sx.
 constexpr int PREP_MAXI = 16;
 __global__ __launch_bounds__(256) void prep_f16x2_wave_kernel(PrepArgs a) {
+  if ((int)blockIdx.x >= a.row_blocks) { fq_transpose_tile(a, blockIdx.x - a.row_blocks); return; }
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   _Float16* whi = a.Whi + (int64_t)n * a.Kp;
@@ -913,12 +943,14 @@ extern "C" size_t spq_prep_f16x2_bytes(int64_t N, int64_t K, int64_t r) {
 extern "C" int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const float* sw, const float* zw,
                                  int w_per_channel, int w_bits, int w_qtype, int w_symmetric, const float* B,
                                  int64_t r, const float* sb, const float* zb, int b_per_channel, int b_bits,
-                                 int b_qtype, int b_symmetric, float scaling, const float* sx, int x_per_channel,
-                                 void* w_prep, size_t w_prep_bytes, float* w_rowscale, spq_stream_t stream) {
+                                 int b_qtype, int b_symmetric, float scaling, const float* A, const float* sa,
+                                 const float* za, int a_per_channel, int a_bits, int a_qtype, int a_symmetric,
+                                 const float* sx, int x_per_channel, void* w_prep, size_t w_prep_bytes,
+                                 float* w_rowscale, float* a_prep, spq_stream_t stream) {
   SPQ_REQUIRE(W && sw && zw && sx && w_prep && w_rowscale, "spq_prepare_f16x2: null pointer");
   SPQ_REQUIRE(N > 0 && K > 0 && r >= 0, "spq_prepare_f16x2: bad shape");
-  SPQ_REQUIRE(r == 0 || (B && sb && zb), "spq_prepare_f16x2: LoRA-B operands missing");
-  SPQ_REQUIRE(w_bits >= 1 && b_bits >= 0, "spq_prepare_f16x2: bad bit-width");
+  SPQ_REQUIRE(r == 0 || (B && sb && zb && A && sa && za && a_prep), "spq_prepare_f16x2: LoRA operands missing");
+  SPQ_REQUIRE(w_bits >= 1 && b_bits >= 0 && a_bits >= 0, "spq_prepare_f16x2: bad bit-width");
   if (!f16x2_shape_ok(1, K, N, r)) { set_error("spq_prepare_f16x2: needs LoRA rank <= 128 and N %% 4 == 0 (got r=%lld N=%lld)", (long long)r, (long long)N); return SPQ_ERR_UNSUPPORTED; }
   const PrepLayout P = make_prep_layout(N, K, r);
   if (w_prep_bytes < P.total || !aligned16(w_prep)) { set_error("spq_prepare_f16x2: buffer too small (%zu < %zu)", w_prep_bytes, P.total); return SPQ_ERR_WORKSPACE; }
@@ -932,8 +964,16 @@ extern "C" int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const flo
   a.w_pc = w_per_channel; a.w_bits = w_bits; a.w_qtype = w_qtype; a.w_sym = w_symmetric;
   a.b_pc = b_per_channel; a.b_bits = b_bits; a.b_qtype = b_qtype; a.b_sym = b_symmetric;
   a.x_pc = x_per_channel; a.scaling = scaling;
+  a.A = A; a.sa = sa; a.za = za; a.aT = a_prep;
+  a.a_pc = a_per_channel; a.a_bits = a_bits; a.a_qtype = a_qtype; a.a_sym = a_symmetric;
+  const int at_blocks = r > 0 ? (int)(((r + 31) / 32) * ((K + 31) / 32)) : 0;
   const bool wave_ok = (K % 4 == 0) && K <= 4 * 64 * PREP_MAXI && aligned16(W) && (!x_per_channel || aligned16(sx)) && r <= 128;
-  if (wave_ok) prep_f16x2_wave_kernel<<<(unsigned)(P.Np / 4), 256, 0, (hipStream_t)stream>>>(a);
-  else prep_f16x2_kernel<<<(unsigned)P.Np, 256, 0, (hipStream_t)stream>>>(a);
+  if (wave_ok) {
+    a.row_blocks = (int)(P.Np / 4);
+    prep_f16x2_wave_kernel<<<(unsigned)(a.row_blocks + at_blocks), 256, 0, (hipStream_t)stream>>>(a);
+  } else {
+    a.row_blocks = (int)P.Np;
+    prep_f16x2_kernel<<<(unsigned)(a.row_blocks + at_blocks), 256, 0, (hipStream_t)stream>>>(a);
+  }
   return check_launch("spq_prepare_f16x2");
 }

@@ -273,7 +273,8 @@ class SPLinearWithLoRA(nn.Module):
         prep.path, prep.w_rowscale = path, None
         prep.r = lora.rank if use_lora else 0
         with torch.no_grad():
-            prep.a = _fq_transposed(lora.quantize_A, lora.lora_A.detach(), 64) if use_lora else None   # [r->64k, K]
+            if path == _lib.PATH_F32 or not use_lora:
+                prep.a = _fq_transposed(lora.quantize_A, lora.lora_A.detach(), 64) if use_lora else None   # [r->64k, K]
             if path == _lib.PATH_F32:
                 prep.w = qw(W.detach())                                                            # [N,K]
                 prep.b = _fq_transposed(lora.quantize_B, lora.lora_B.detach()) if use_lora else None  # [N,r]
@@ -293,7 +294,15 @@ class SPLinearWithLoRA(nn.Module):
         n_pad = (N + 127) // 128 * 128
         prep.w_rowscale = torch.empty(n_pad, dtype=torch.float32, device=W.device)
         qb = lora.quantize_B if use_lora else None
+        qa = lora.quantize_A if use_lora else None
         B = lora.lora_B.detach().contiguous() if use_lora else None
+        A = lora.lora_A.detach().contiguous() if use_lora else None
+        if use_lora:
+            r_pad = (r + 63) // 64 * 64
+            if prep.a is None or tuple(prep.a.shape) != (r_pad, K) or prep.a.device != W.device:
+                prep.a = torch.zeros(r_pad, K, dtype=torch.float32, device=W.device)     # rows >= r stay zero
+            if qa.scale.numel() not in (1, r):
+                raise RuntimeError(f"LoRA-A scale of shape {tuple(qa.scale.shape)} does not fit rank {r}")
         for q, n_expected, what in ((qw, N, "weight"), (qb, N, "LoRA-B")):
             if q is not None and q.scale.numel() not in (1, n_expected):
                 raise RuntimeError(f"{what} scale of shape {tuple(q.scale.shape)} does not fit {n_expected} output features")
@@ -304,8 +313,13 @@ class SPLinearWithLoRA(nn.Module):
                 _lib.ptr(B), r, _lib.ptr(qb.scale) if qb else None, _lib.ptr(qb.zero_point) if qb else None,
                 (1 if qb.scale.numel() > 1 else 0) if qb else 0, int(qb.num_bits) if qb else 0,
                 _lib.QTYPE_CODE[qb.quantizer_type] if qb else 0, (1 if qb.symmetric else 0) if qb else 1,
-                float(lora.scaling) if use_lora else 0.0, qx.scale.data_ptr(), 1 if qx.scale.numel() > 1 else 0,
-                prep.w.data_ptr(), prep.w.numel(), prep.w_rowscale.data_ptr(), _lib.stream_ptr(W.device))
+                float(lora.scaling) if use_lora else 0.0,
+                _lib.ptr(A), _lib.ptr(qa.scale) if qa else None, _lib.ptr(qa.zero_point) if qa else None,
+                (1 if qa.scale.numel() > 1 else 0) if qa else 0, int(qa.num_bits) if qa else 0,
+                _lib.QTYPE_CODE[qa.quantizer_type] if qa else 0, (1 if qa.symmetric else 0) if qa else 1,
+                qx.scale.data_ptr(), 1 if qx.scale.numel() > 1 else 0,
+                prep.w.data_ptr(), prep.w.numel(), prep.w_rowscale.data_ptr(), _lib.ptr(prep.a) if use_lora else None,
+                _lib.stream_ptr(W.device))
         _lib.check(rc, "spq_prepare_f16x2")
         prep.b = prep.w      # LoRA-B limbs live inside the same buffer
 
