@@ -42,7 +42,8 @@ enum spq_qtype { SPQ_MINMAX = 0, SPQ_LOG = 1 };
 enum spq_path {
   SPQ_PATH_AUTO = 0,
   SPQ_PATH_F32 = 1,   /* fp32-input MFMA on dequantised fp32 operands: always valid */
-  SPQ_PATH_F16X2 = 2  /* exact integer levels (fp16) x 2-limb fp16 weights on f16 MFMA: minmax, symmetric, bits<=12 */
+  SPQ_PATH_F16X2 = 2, /* exact integer levels (fp16) x 2-limb fp16 weights on f16 MFMA: minmax, symmetric, bits<=12 */
+  SPQ_PATH_U8X2 = 3   /* same arithmetic, levels stored as bytes (bits<=8), 3-slot LDS ring; same prepared operands as F16X2 */
 };
 
 typedef void* spq_stream_t;

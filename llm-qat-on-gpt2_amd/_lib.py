@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspq.so")
 
 MINMAX, LOG = 0, 1
-PATH_AUTO, PATH_F32, PATH_F16X2 = 0, 1, 2
+PATH_AUTO, PATH_F32, PATH_F16X2, PATH_U8X2 = 0, 1, 2, 3
 QTYPE_CODE = {"minmax": MINMAX, "log": LOG}
 
 _lib = None

@@ -237,8 +237,10 @@ class SPLinearWithLoRA(nn.Module):
                   and (not use_lora or lora.rank <= 128))
         if self.operand_path == _lib.PATH_AUTO:
             return _lib.PATH_F16X2 if f16_ok else _lib.PATH_F32
-        if self.operand_path == _lib.PATH_F16X2 and not f16_ok:
+        if self.operand_path in (_lib.PATH_F16X2, _lib.PATH_U8X2) and not f16_ok:
             return _lib.PATH_F32            # e.g. calibration forwards (raw x) of a layer pinned to F16X2
+        if self.operand_path == _lib.PATH_U8X2 and qx.num_bits > 8:
+            return _lib.PATH_F16X2
         return self.operand_path
 
     def _operands(self, key, qx, qw, lora, use_lora, quantize_input):
@@ -256,7 +258,7 @@ class SPLinearWithLoRA(nn.Module):
         W = self.linear.weight
         path = self._choose_path(qx, qw, lora, use_lora, quantize_input)
         sig = [path, use_lora, _sig(W), qw._epoch, _sig(qw.scale), _sig(qw.zero_point)]
-        if path == _lib.PATH_F16X2:
+        if path in (_lib.PATH_F16X2, _lib.PATH_U8X2):
             sig += [qx._epoch, _sig(qx.scale)]
         if use_lora:
             for q, t in ((lora.quantize_A, lora.lora_A), (lora.quantize_B, lora.lora_B)):

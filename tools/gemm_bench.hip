@@ -40,6 +40,27 @@ int main(int argc, char** argv) {
   hipMemset(ri, 0, M * 4); hipMemset(rs, 0, N * 4); hipMemset(bias, 0, N * 4);
   g.rowinv = ri; g.rowscale = rs; g.bias = bias; g.y = y; g.M = M; g.N = N; g.Kp = K; g.Rp = R;
   g.tiles_m = M / GM; g.tiles_n = N / GN;
+  {
+    GemmU8Args u;
+    std::vector<unsigned char> hb((size_t)M * K); for (auto& v : hb) v = (unsigned char)(121 + rng() % 15);
+    unsigned char* dq; hipMalloc(&dq, hb.size()); hipMemcpy(dq, hb.data(), hb.size(), hipMemcpyHostToDevice);
+    u.qx = dq; u.thi = g.thi; u.tlo = g.tlo; u.Whi = g.Whi; u.Wlo = g.Wlo; u.Bhi = g.Bhi; u.Blo = g.Blo;
+    u.rowinv = ri; u.rowscale = rs; u.bias = bias; u.y = y; u.M = M; u.N = N; u.Kp = K; u.Rp = R; u.tiles_m = M / GM; u.tiles_n = N / GN;
+    auto runu = [&](auto kern) {
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, U8_LDS);
+      hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+      for (int i = 0; i < 5; ++i) kern<<<gemm_grid(u.tiles_m * u.tiles_n), GEMM_THREADS, U8_LDS>>>(u);
+      hipEventRecord(a);
+      for (int i = 0; i < 50; ++i) kern<<<gemm_grid(u.tiles_m * u.tiles_n), GEMM_THREADS, U8_LDS>>>(u);
+      hipEventRecord(b); hipEventSynchronize(b);
+      float ms; hipEventElapsedTime(&ms, a, b); return ms / 50 * 1e3f;
+    };
+    { GemmU8Args v = u; GemmU8Args keep = u; v.Kp = 64; u = v; printf("skeleton only, K=64 (5 stages/tile): %.1f us; ", runu(gemm_u8x2_kernel<26>)); v.Rp = 0; u = v; printf("K=64, no LoRA (1 stage/tile): %.1f us\n", runu(gemm_u8x2_kernel<26>)); u = keep; }
+    for (int rep = 0; rep < 2; ++rep)
+      printf("u8x2: full %.1f | no-copies %.1f | no-compute %.1f | no-stores %.1f | no-copies,no-stores %.1f | stores only %.1f | skeleton only %.1f us\n",
+             runu(gemm_u8x2_kernel<0>), runu(gemm_u8x2_kernel<2>),
+             runu(gemm_u8x2_kernel<8>), runu(gemm_u8x2_kernel<16>), runu(gemm_u8x2_kernel<18>), runu(gemm_u8x2_kernel<10>), runu(gemm_u8x2_kernel<26>));
+  }
   unsigned long long* dbg; hipMalloc(&dbg, 256 * 16); g.dbg = dbg;
   auto clock_of = [&](auto runner) {
     runner();
