@@ -1,0 +1,229 @@
+"""GPU: the other linears of BASELINE configs 2-5 (c_attn, attn c_proj, mlp c_proj, GPT-2-medium dims, 8-bit, log 6-bit),
+a GPT-2 block assembled from the drop-in layers, autograd through the composed path, and size-independent properties."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import assert_close_y
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import llm_qat_on_gpt2_amd as p
+    p._lib.load()
+    return p
+
+
+def make_pair(pkg, M, K, N, r, bits, qtype, per_channel, seed, batch=4, alpha=None):
+    """(product layer on GPU, calibrated oracle layer, activations)"""
+    from oracle import ref_cpu as O
+    W, bias, A, B, x0, x1 = O.make_workload(M, K, N, r, seed=seed, batch=batch)
+    alpha = r if alpha is None else alpha
+    ol = O.build_calibrated_layer(W, bias, A, B, [x0, x1], bits, qtype, per_channel, alpha, r)
+    layer = pkg.SPLinearWithLoRA(K, N, [bits, 32], {bits: r, 32: 0}, {bits: alpha, 32: 0}, {bits: qtype, 32: None},
+                                 per_channel=per_channel)
+    key = f"{bits}bit"
+    with torch.no_grad():
+        layer.linear.weight.copy_(W); layer.linear.bias.copy_(bias)
+        layer.lora_adapters[key].lora_A.copy_(A); layer.lora_adapters[key].lora_B.copy_(B)
+    layer = layer.to(DEV).eval()
+    layer.set_precision(bits)
+    pkg.calibrate_layer(layer, bits, [x0.to(DEV), x1.to(DEV)])
+    return layer, ol, x0, x1
+
+
+SHAPES = [
+    # name,                M,    K,    N,   r, bits, qtype,   per_channel
+    ("cfg2_cfc_8bit_pc",   4096, 768,  3072, 64, 8, "minmax", True),      # BASELINE configs[1]
+    ("cfg2_cfc_8bit_pt",   4096, 768,  3072, 64, 8, "minmax", False),
+    ("c_attn_4bit",        2048, 768,  2304, 64, 4, "minmax", True),      # configs[2] block linears
+    ("attn_cproj_4bit",    2048, 768,  768,  64, 4, "minmax", True),
+    ("mlp_cproj_4bit",     2048, 3072, 768,  64, 4, "minmax", True),      # K = 3072: four activation panels
+    ("medium_cfc_log6",    1024, 1024, 4096, 64, 6, "log",    True),      # configs[4]: GPT-2-medium dims, log 6-bit
+    ("medium_cproj_log6",  1024, 4096, 1024, 64, 6, "log",    True),
+    ("ragged_rank16",      1000, 320,  200,  16, 4, "minmax", True),      # edge tiles in M and N, rank < 64
+    ("tiny",               3,    64,   8,    8,  3, "minmax", False),
+]
+
+
+@pytest.mark.parametrize("name,M,K,N,r,bits,qtype,pc", SHAPES, ids=[s[0] for s in SHAPES])
+def test_linear_shapes_against_oracle(pkg, name, M, K, N, r, bits, qtype, pc):
+    batch = 4 if M % 4 == 0 else 1
+    layer, ol, x0, x1 = make_pair(pkg, M, K, N, r, bits, qtype, pc, seed=hash(name) % 1000, batch=batch)
+    key = f"{bits}bit"
+    if qtype == "minmax":
+        assert torch.equal(layer.quantizers_input[key].scale.cpu().reshape(-1), ol.qx.scale.reshape(-1))
+        assert torch.equal(layer.quantizers_weight[key].scale.cpu().reshape(-1), ol.qw.scale.reshape(-1))
+        lv = layer.quantizers_input[key].quantize_levels(x1.to(DEV)).cpu()
+        assert torch.equal(lv, ol.qx.levels(x1).to(torch.int32)), "activation levels not bit-exact"
+    with torch.no_grad():
+        y = layer(x1.to(DEV))
+        layer.calibration_mode = True
+        base = layer(x1.to(DEV))
+        layer.calibration_mode = False
+    tol = 1e-5 if qtype == "minmax" else 2e-5
+    assert_close_y(y, ol.forward(x1), f"{name}.y", tol)
+    assert_close_y(base, ol.forward(x1, calibration_mode=True), f"{name}.base", tol)
+    want = pkg._lib.PATH_F16X2 if qtype == "minmax" else pkg._lib.PATH_F32
+    assert layer._last_path == want
+
+
+def test_properties_at_headline_size(pkg):
+    """Size-independent checks at BASELINE's full size (no oracle needed): determinism, row independence (each token's
+    output depends on its own row only), additivity in the bias, and precision switching 4 <-> 32 <-> 4."""
+    M, K, N, r, bits = 8192, 768, 3072, 64, 4
+    layer, ol, x0, x1 = make_pair(pkg, M, K, N, r, bits, "minmax", True, seed=0, batch=8)
+    xd = x0.to(DEV)
+    with torch.no_grad():
+        y = layer(xd)
+        assert torch.equal(y, layer(xd))
+        perm = torch.randperm(M, device=DEV)
+        y_perm = layer(xd.reshape(M, K)[perm].reshape(8, M // 8, K))
+        assert torch.equal(y_perm.reshape(M, N), y.reshape(M, N)[perm]), "rows are not independent"
+        sub = layer(xd[:, :100].contiguous())
+        assert torch.equal(sub, y[:, :100]), "a sub-batch gives different values"
+        b0 = layer.linear.bias.clone()
+        layer.linear.bias.add_(1.0)
+        y_b = layer(xd)
+        assert float((y_b - y - 1.0).abs().max()) < 2e-6
+        layer.linear.bias.copy_(b0)                                       # (b + 1) - 1 != b in fp32
+        layer.set_precision(32)
+        y32 = layer(xd)
+        assert torch.allclose(y32, F.linear(xd, layer.linear.weight, layer.linear.bias))
+        layer.set_precision(bits)
+        assert torch.equal(layer(xd), y), "precision switch 4 -> 32 -> 4 changed the 4-bit output"
+
+
+def test_operand_cache_tracks_weight_and_scale_changes(pkg):
+    layer, ol, x0, x1 = make_pair(pkg, 512, 128, 256, 16, 4, "minmax", True, seed=5)
+    xd = x0.to(DEV)
+    with torch.no_grad():
+        y0 = layer(xd)
+        prep = layer._prepared[("4bit", layer._last_path)]
+        sig0 = prep.sig
+        assert torch.equal(layer(xd), y0) and layer._prepared[("4bit", layer._last_path)].sig == sig0   # reused
+        layer.lora_adapters["4bit"].lora_B.mul_(2.0)                     # in-place optimizer-style update -> version bump
+        pkg.calibration.calibrate_lora_only(layer, 4)
+        y1 = layer(xd)
+        assert not torch.equal(y1, y0) and layer._prepared[("4bit", layer._last_path)].sig != sig0
+        layer.linear.weight.data.mul_(1.5)                                # write through .data: not visible to the cache ...
+        layer.invalidate_operand_cache()                                  # ... until told
+        q = layer.quantizers_weight["4bit"]; q.start_calibration(); q(layer.linear.weight.data); q.finish_calibration()
+        y2 = layer(xd)
+        assert not torch.equal(y2, y1)
+        layer.train()                                                     # training mode: operands rebuilt every call
+        assert torch.equal(layer(xd), y2)
+
+
+def test_autograd_composed_path_matches_fused_forward_and_has_ste_grads(pkg):
+    layer, ol, x0, x1 = make_pair(pkg, 256, 128, 192, 16, 4, "minmax", True, seed=7)
+    xd = x0.to(DEV)
+    with torch.no_grad():
+        y_fused = layer(xd)
+    lo = layer.lora_adapters["4bit"]
+    layer.linear.weight.requires_grad_(False); layer.linear.bias.requires_grad_(False)
+    xg = xd.clone().requires_grad_(True)
+    y = layer(xg)                                                         # grad required -> composed autograd path
+    assert_close_y(y, y_fused.cpu(), "composed vs fused", 1e-5)
+    g = torch.randn_like(y)
+    y.backward(g)
+    # straight-through: d/dx = g . FQ(W) + s * (g . FQ(B)^T) . FQ(A)^T   (quantization_methods.py:25-28 un-masked STE)
+    with torch.no_grad():
+        wq = layer.quantizers_weight["4bit"](layer.linear.weight)
+        aq = lo.quantize_A(lo.lora_A); bq = lo.quantize_B(lo.lora_B)
+        gx = g @ wq + lo.scaling * ((g @ bq.t()) @ aq.t())
+        gA = lo.scaling * (xd.reshape(-1, 128).t() @ (g.reshape(-1, 192) @ bq.t()))
+    assert torch.allclose(xg.grad, gx, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(lo.lora_A.grad, gA, rtol=1e-3, atol=1e-4)
+    assert lo.lora_B.grad is not None and layer.linear.weight.grad is None
+
+
+class MiniBlock(torch.nn.Module):
+    """A GPT-2 block in the shape of the reference's SPBlock (models_sp.py:130-171): LN -> c_attn -> causal attention
+    -> c_proj -> +res -> LN -> c_fc -> GELU -> c_proj -> +res; the four linears are the drop-in layers."""
+
+    def __init__(self, pkg, n_embd, n_head, bits, qtype, r):
+        super().__init__()
+        mk = lambda i, o: pkg.SPLinearWithLoRA(i, o, [bits, 32], {bits: r, 32: 0}, {bits: r, 32: 0}, {bits: qtype, 32: None})
+        self.ln_1, self.ln_2 = torch.nn.LayerNorm(n_embd), torch.nn.LayerNorm(n_embd)
+        self.c_attn, self.c_proj = mk(n_embd, 3 * n_embd), mk(n_embd, n_embd)
+        self.c_fc, self.mlp_proj = mk(n_embd, 4 * n_embd), mk(4 * n_embd, n_embd)
+        self.n_head = n_head
+
+    def set_precision(self, bits):
+        for m in (self.c_attn, self.c_proj, self.c_fc, self.mlp_proj):
+            m.set_precision(bits)
+
+    def forward(self, x, lin=None):
+        lin = lin or (lambda m, v: m(v))
+        B, T, C = x.shape
+        qkv = lin(self.c_attn, self.ln_1(x))
+        q, k, v = qkv.split(C, dim=2)
+        hd = C // self.n_head
+        q, k, v = (t.view(B, T, self.n_head, hd).transpose(1, 2) for t in (q, k, v))
+        att = (q @ k.transpose(-2, -1)) / math.sqrt(hd)
+        att = att.masked_fill(torch.tril(torch.ones(T, T, device=x.device)) == 0, float("-inf")).softmax(dim=-1)
+        a = (att @ v).transpose(1, 2).contiguous().view(B, T, C)
+        x = x + lin(self.c_proj, a)
+        return x + lin(self.mlp_proj, F.gelu(lin(self.c_fc, self.ln_2(x))))
+
+
+def test_block_of_four_linears_with_model_level_calibration(pkg):
+    """BASELINE configs[2] in miniature: calibrate_model() over a block (weights, inputs through the block forward with
+    LoRA off, LoRA factors), then the block output against the same block with every linear replaced by the oracle."""
+    from oracle import ref_cpu as O
+    torch.manual_seed(0)
+    C, H, bits, r, B, T = 128, 4, 4, 16, 4, 64
+    blk = MiniBlock(pkg, C, H, bits, "minmax", r)
+    with torch.no_grad():
+        for m in (blk.c_attn, blk.c_proj, blk.c_fc, blk.mlp_proj):
+            m.linear.weight.normal_(0, 0.05); m.linear.bias.normal_(0, 0.02)
+            m.lora_adapters[f"{bits}bit"].lora_B.normal_(0, 0.02)
+    cpu_state = {k: v.clone() for k, v in blk.state_dict().items()}
+    blk = blk.to(DEV).eval()
+    xs = [torch.randn(B, T, C) for _ in range(3)]
+    n = pkg.calibrate_model(blk, bits, [x.to(DEV) for x in xs[:2]])
+    assert n == 0                                                          # single process: no collective
+    for m in (blk.c_attn, blk.c_proj, blk.c_fc, blk.mlp_proj):
+        assert m.quantizers_input[f"{bits}bit"].calibrated and not m.calibration_mode
+    with torch.no_grad():
+        y = blk(xs[2].to(DEV)).cpu()
+
+    # oracle twin: same protocol on CPU (train_sp.py:47-163)
+    ref = MiniBlock(pkg, C, H, bits, "minmax", r)
+    ref.load_state_dict(cpu_state)
+    layers = {}
+    for name in ("c_attn", "c_proj", "c_fc", "mlp_proj"):
+        m = getattr(ref, name); lo = m.lora_adapters[f"{bits}bit"]
+        W, b, A, Bm = (t.detach() for t in (m.linear.weight, m.linear.bias, lo.lora_A, lo.lora_B))
+        layers[m] = O.OracleLayer(W, b, A, Bm, O.QuantState(bits, "minmax", -1, True), O.QuantState(bits, "minmax", 0, True).calibrate_on(W),
+                                  O.QuantState(bits, "minmax", 1, True).calibrate_on(A), O.QuantState(bits, "minmax", 1, True).calibrate_on(Bm),
+                                  lo.scaling, bits)
+    state = {"calib": True}
+    lin = lambda m, v: layers[m].forward(v, calibration_mode=state["calib"])
+    with torch.no_grad():
+        for ol in layers.values():
+            ol.qx.start()
+        for x in xs[:2]:
+            ref(x, lin)
+        for ol in layers.values():
+            ol.qx.finish()
+        state["calib"] = False
+        y_ref = ref(xs[2], lin)
+    # LayerNorm / softmax / GELU run on two back ends (ROCm vs CPU ATen), so the linears' inputs differ in the last bits and
+    # an occasional activation level flips (quantization is discontinuous): compare in the L2 sense, plus the scales.
+    for name in ("c_attn", "c_proj", "c_fc", "mlp_proj"):
+        got = getattr(blk, name).quantizers_input[f"{bits}bit"].scale.cpu().reshape(-1)
+        want = layers[getattr(ref, name)].qx.scale.reshape(-1)
+        assert torch.allclose(got, want, rtol=1e-5, atol=0), name
+    # one flipped 4-bit level moves a token's output by ~1e-2, so count tokens: all but a handful must agree closely
+    rms = float(y_ref.pow(2).mean().sqrt())
+    row_err = ((y - y_ref).abs() / (1e-4 * y_ref.abs() + 1e-4 * rms)).amax(dim=-1).reshape(-1)
+    bad = int((row_err > 1.0).sum())
+    assert bad <= 0.02 * row_err.numel(), f"{bad} of {row_err.numel()} tokens differ"
+    assert float((y - y_ref).norm() / y_ref.norm()) < 5e-3
