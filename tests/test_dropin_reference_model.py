@@ -1,0 +1,82 @@
+"""CPU, build container only (skipped where /root/reference is absent, e.g. on the GPU box): the drop-in claim itself.
+The reference's own GPT-2 assembly (part1_switchable_precision/models_sp.py) is imported with its `SPLinearWithLoRA`
+replaced by this build's class -- the one-line swap of INTEGRATION.md -- and must construct, expose the same state-dict,
+fan out set_precision() and toggle calibration_mode exactly as with the reference's class.  No compute (no GPU here)."""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "part1_switchable_precision")),
+                                reason="reference checkout not present (only the build container has it)")
+
+
+def _config():
+    from transformers import GPT2Config
+    cfg = GPT2Config(vocab_size=97, n_positions=32, n_embd=32, n_layer=2, n_head=4)
+    cfg.bit_widths = [4, 6, 32]
+    cfg.lora_rank_per_bit = {4: 4, 6: 4, 32: 0}
+    cfg.lora_alpha_per_bit = {4: 4, 6: 4, 32: 0}
+    cfg.quantizer_per_bit = {4: "minmax", 6: "log", 32: None}
+    cfg.activation_bits_per_bit = {4: 4, 6: 6, 32: 32}
+    cfg.per_channel_quantization = True
+    cfg.layer_norm_epsilon = 1e-5
+    cfg.embd_pdrop = 0.0
+    return cfg
+
+
+def _build(swap):
+    sys.dont_write_bytecode = True
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for name in [m for m in sys.modules if m.startswith("part1_switchable_precision")]:
+        del sys.modules[name]
+    models = importlib.import_module("part1_switchable_precision.models_sp")
+    if swap:
+        import llm_qat_on_gpt2_amd as pkg
+        # what editing models_sp.py:14 (`from part1_switchable_precision.lora import SPLinearWithLoRA`) to import this
+        # build's class does: rebind the name the model code instantiates
+        models.SPLinearWithLoRA = pkg.SPLinearWithLoRA
+    torch.manual_seed(0)
+    return models.SPLMHeadModel(_config())
+
+
+def test_reference_model_builds_on_the_dropin_layers():
+    import llm_qat_on_gpt2_amd as pkg
+    ref = _build(swap=False)
+    mine = _build(swap=True)
+    layers = [m for m in mine.modules() if m.__class__.__name__ == "SPLinearWithLoRA"]
+    assert len(layers) == 8 and all(isinstance(m, pkg.SPLinearWithLoRA) for m in layers)      # 4 per block x 2 blocks
+    sd_ref, sd_mine = ref.state_dict(), mine.state_dict()
+    assert list(sd_ref.keys()) == list(sd_mine.keys())
+    assert {k: tuple(v.shape) for k, v in sd_ref.items()} == {k: tuple(v.shape) for k, v in sd_mine.items()}
+    mine.load_state_dict(sd_ref, strict=True)                                               # reference checkpoint loads
+    # set_precision fan-out (models_sp.py:224-234, 147-152, 52-56, 116-122)
+    assert mine.set_precision(4) == 4 and all(m.current_bits == 4 for m in layers)
+    with pytest.raises(ValueError):
+        mine.set_precision(5)
+    mine.set_precision(32)
+    assert all(m.current_bits == 32 for m in layers)
+    # calibration toggles match on the class NAME (models_sp.py:236-246)
+    mine.disable_lora_for_calibration()
+    assert all(m.calibration_mode for m in layers)
+    mine.enable_lora_after_calibration()
+    assert not any(m.calibration_mode for m in layers)
+    # the teacher path (32 bit) is plain F.linear and runs anywhere: same logits as the reference model with the same weights
+    ref.set_precision(32); ref.eval(); mine.eval()
+    ids = torch.randint(0, 97, (2, 16))
+    with torch.no_grad():
+        out_ref, out_mine = ref(ids), mine(ids)
+    lr = out_ref["logits"] if isinstance(out_ref, dict) else (out_ref.logits if hasattr(out_ref, "logits") else out_ref[0])
+    lm = out_mine["logits"] if isinstance(out_mine, dict) else (out_mine.logits if hasattr(out_mine, "logits") else out_mine[0])
+    assert torch.allclose(lr, lm, atol=1e-6)
+    # below 32 bits the layers are HIP-only: a CPU tensor is refused loudly instead of silently falling back
+    mine.set_precision(4)
+    for m in layers:
+        for q in (m.quantizers_weight["4bit"], m.quantizers_input["4bit"]):
+            q.calibrated = True
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        mine(ids)
