@@ -48,6 +48,12 @@ SHAPES = [
     ("medium_cproj_log6",  1024, 4096, 1024, 64, 6, "log",    True),
     ("ragged_rank16",      1000, 320,  200,  16, 4, "minmax", True),      # edge tiles in M and N, rank < 64
     ("tiny",               3,    64,   8,    8,  3, "minmax", False),
+    ("rank128",            512,  256,  384,  128, 4, "minmax", True),     # two 64-wide LoRA blocks
+    ("rank100_K72",        300,  72,   260,  100, 4, "minmax", True),     # rank and K not multiples of 64: generic activation pass
+    ("bits2",              512,  256,  256,  32, 2, "minmax", True),
+    ("bits12_fp16_levels", 512,  256,  256,  32, 12, "minmax", True),     # largest width of the exact-integer path
+    ("bits13_falls_to_f32", 256, 128,  128,  16, 13, "minmax", True),
+    ("log4_per_tensor",    512,  256,  256,  32, 4, "log",    False),
 ]
 
 
@@ -69,7 +75,7 @@ def test_linear_shapes_against_oracle(pkg, name, M, K, N, r, bits, qtype, pc):
     tol = 1e-5 if qtype == "minmax" else 2e-5
     assert_close_y(y, ol.forward(x1), f"{name}.y", tol)
     assert_close_y(base, ol.forward(x1, calibration_mode=True), f"{name}.base", tol)
-    want = pkg._lib.PATH_F16X2 if qtype == "minmax" else pkg._lib.PATH_F32
+    want = pkg._lib.PATH_F16X2 if (qtype == "minmax" and bits <= 12) else pkg._lib.PATH_F32
     assert layer._last_path == want
 
 
@@ -97,6 +103,24 @@ def test_properties_at_headline_size(pkg):
         assert torch.allclose(y32, F.linear(xd, layer.linear.weight, layer.linear.bias))
         layer.set_precision(bits)
         assert torch.equal(layer(xd), y), "precision switch 4 -> 32 -> 4 changed the 4-bit output"
+
+
+def test_config3_token_count_runs_and_is_consistent(pkg):
+    """BASELINE configs[2] token count (batch 32 x seq 1024 = 32768 tokens) on c_fc: halves of the batch computed
+    separately must reproduce the full-batch output bit for bit (rows are independent), and a sample of rows is checked
+    against the oracle."""
+    from oracle import ref_cpu as O
+    M, K, N, r, bits = 32768, 768, 3072, 64, 4
+    layer, ol, x0, x1 = make_pair(pkg, 2048, K, N, r, bits, "minmax", True, seed=3, batch=2)
+    g = torch.Generator().manual_seed(99)
+    xb = torch.randn(32, 1024, K, generator=g)
+    with torch.no_grad():
+        y = layer(xb.to(DEV))
+        y_lo = layer(xb[:16].to(DEV)); y_hi = layer(xb[16:].to(DEV))
+    assert tuple(y.shape) == (32, 1024, N)
+    assert torch.equal(y[:16], y_lo) and torch.equal(y[16:], y_hi)
+    rows = xb.reshape(M, K)[::97][:256]
+    assert_close_y(y.reshape(M, N)[::97][:256].cpu(), ol.forward(rows).reshape(256, N), "config3 sample rows", 1e-5)
 
 
 def test_operand_cache_tracks_weight_and_scale_changes(pkg):
