@@ -162,6 +162,16 @@ class SPLinearWithLoRA(nn.Module):
             x.requires_grad or self.linear.weight.requires_grad
             or (self.linear.bias is not None and self.linear.bias.requires_grad)
             or (lora.enabled and not self.calibration_mode and (lora.lora_A.requires_grad or lora.lora_B.requires_grad)))
+        if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
+            x = x.float()       # under torch.autocast the producer may hand over half precision; the kernels are fp32
+        collecting = qw.collecting_stats or qx.collecting_stats or (
+            lora.enabled and (lora.quantize_A.collecting_stats or lora.quantize_B.collecting_stats))
+        if needs_grad and not collecting and x.is_cuda:
+            # fused forward + straight-through backward on the MFMA kernels
+            use_lora = (not self.calibration_mode) and lora.enabled and lora.scaling != 0
+            return _SPLinearFunction.apply(x, self.linear.weight, self.linear.bias,
+                                           lora.lora_A if use_lora else None, lora.lora_B if use_lora else None,
+                                           self, key)
         if needs_grad or qw.collecting_stats or (lora.enabled and (lora.quantize_A.collecting_stats or lora.quantize_B.collecting_stats)):
             return self._forward_composed(x, qx, qw, lora)
         return self._forward_fused(x, key, qx, qw, lora)
@@ -324,6 +334,83 @@ class SPLinearWithLoRA(nn.Module):
                 _lib.stream_ptr(W.device))
         _lib.check(rc, "spq_prepare_f16x2")
         prep.b = prep.w      # LoRA-B limbs live inside the same buffer
+
+
+class _SPLinearFunction(torch.autograd.Function):
+    """Fused forward (``spq_linear_lora_fwd``) with the reference's straight-through backward
+    (quantization_methods.py:25-28 un-masked identity for minmax, :82-90 clamp to [-10, 10] for log):
+
+        d/dx     = STE_x( g . FQ(W) ) + s * (g . FQ(B)^T) . FQ(A)^T         [one spq_gemm_f32_nt launch, two segments]
+        d/dA     = STE_A( s * x^T . (g . FQ(B)^T) )        d/dB = STE_B( s * (x . FQ(A))^T . g )
+        d/dW     = STE_W( g^T . FQ(x) )   (only if the base weight is trainable; main_sp.py:83 freezes it)
+        d/dbias  = sum_m g
+
+    The M-contractions (d/dA, d/dB, d/dW) are plain library GEMMs (torch-ROCm); the N- and r-contractions run on the
+    fp32-MFMA kernel of this library.
+    """
+
+    @staticmethod
+    def forward(ctx, x, W, bias, A, B, module, key):
+        qx, qw, lora = module.quantizers_input[key], module.quantizers_weight[key], module.lora_adapters[key]
+        with torch.no_grad():
+            y = module._forward_fused(x, key, qx, qw, lora)
+        ctx.module, ctx.key = module, key
+        ctx.use_lora = A is not None
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        module, key = ctx.module, ctx.key
+        (x,) = ctx.saved_tensors
+        qx, qw, lora = module.quantizers_input[key], module.quantizers_weight[key], module.lora_adapters[key]
+        K, N = module.in_features, module.out_features
+        need_x, need_W, need_b, need_A, need_B = ctx.needs_input_grad[:5]
+        g2 = g.contiguous().float().reshape(-1, N)
+        x2 = x.detach().contiguous().reshape(-1, K)
+        M = x2.shape[0]
+        gx = gW = gb = gA = gB = None
+
+        def ste(grad, q):
+            return torch.clamp(grad, -10, 10) if q.quantizer_type == 'log' else grad
+
+        with torch.no_grad():
+            lib = _lib.load()
+            stream = _lib.stream_ptr(x2.device)
+            s = float(lora.scaling) if ctx.use_lora else 0.0
+            if ctx.use_lora:
+                aq = lora.quantize_A(lora.lora_A.detach())                       # [K, r]
+                bq = lora.quantize_B(lora.lora_B.detach())                       # [r, N]
+                r = aq.shape[1]
+                gt = _gemm_nt(g2, bq.contiguous())                               # g . FQ(B)^T  -> [M, r]
+            if need_x:
+                wq_t = qw(module.linear.weight.detach()).t().contiguous()        # FQ(W)^T [K, N], N contiguous
+                gx = torch.empty(M, K, dtype=torch.float32, device=x2.device)
+                log_x = qx.quantizer_type == 'log' and qx.num_bits < 32 and not qx.collecting_stats
+                with torch.cuda.device(x2.device):
+                    if ctx.use_lora and not log_x:                               # both terms in one launch
+                        rc = lib.spq_gemm_f32_nt(g2.data_ptr(), N, wq_t.data_ptr(), N, N, gt.data_ptr(), r,
+                                                 aq.contiguous().data_ptr(), r, r, s, None, gx.data_ptr(), K, M, K, stream)
+                    else:
+                        rc = lib.spq_gemm_f32_nt(g2.data_ptr(), N, wq_t.data_ptr(), N, N, None, 0, None, 0, 0, 1.0, None,
+                                                 gx.data_ptr(), K, M, K, stream)
+                _lib.check(rc, "spq_gemm_f32_nt(backward)")
+                if log_x:                                                        # the clamp applies to the quantizer path only
+                    gx = torch.clamp(gx, -10, 10)
+                    if ctx.use_lora:
+                        gx = gx + s * _gemm_nt(gt, aq.contiguous())
+                gx = gx.view(x.shape)
+            if ctx.use_lora and need_A:
+                gA = ste(s * (x2.t() @ gt), lora.quantize_A)
+            if ctx.use_lora and need_B:
+                t = _gemm_nt(x2, aq.t().contiguous())                            # x . FQ(A)  -> [M, r]
+                gB = ste(s * (t.t() @ g2), lora.quantize_B)
+            if need_W:
+                xq = qx(x2) if (qx.num_bits < 32 and qx.calibrated and not qx.collecting_stats) else x2
+                gW = ste(g2.t() @ xq.reshape(-1, K), qw)
+            if need_b:
+                gb = g2.sum(dim=0)
+        return gx, gW, gb, gA, gB, None, None
 
 
 def _fq_transposed(q: LearnableFakeQuantize, t: torch.Tensor, pad_rows_to: int = 1) -> torch.Tensor:

@@ -241,6 +241,25 @@ def sp_linear_forward(x, W, bias, qx: QuantState, qw: QuantState, A=None, B=None
     return base + lora_forward(x, A, B, qA, qB, scaling)                       # :149-150
 
 
+def sp_linear_backward(layer: "OracleLayer", x, g, calibration_mode: bool = False):
+    """Closed form of what autograd gives the reference for one layer with the base weight frozen (main_sp.py:83):
+    straight-through estimators -- identity for minmax (quantization_methods.py:25-28), clamp(grad, -10, 10) for log
+    (:82-90) -- around F.linear and the two LoRA matmuls.  Returns (grad_x, grad_lora_A, grad_lora_B)."""
+    def ste(grad, q):
+        return torch.clamp(grad, -10, 10) if q.qtype == "log" else grad
+    K, N = layer.W.shape[1], layer.W.shape[0]
+    g2, x2 = g.reshape(-1, N), x.reshape(-1, K)
+    gx = ste(g2 @ layer.qw(layer.W), layer.qx)                                 # through F.linear, then the input quantizer
+    if calibration_mode or layer.scaling == 0:
+        return gx.reshape(x.shape), None, None
+    aq, bq = layer.qA(layer.A), layer.qB(layer.B)
+    gt = (g2 * layer.scaling) @ bq.t()                                         # d/d(x@Aq) after "* scaling" (lora.py:53)
+    gx = gx + gt @ aq.t()                                                      # the LoRA branch sees the raw x
+    gA = ste(x2.t() @ gt, layer.qA)
+    gB = ste((x2 @ aq).t() @ (g2 * layer.scaling), layer.qB)
+    return gx.reshape(x.shape), gA, gB
+
+
 # --------------------------------------------------------------------------------------------------
 # Synthetic workload of BASELINE.md §3 / SURVEY.md §8(d) -- shared by tests and bench.py's CPU leg.
 # --------------------------------------------------------------------------------------------------

@@ -131,6 +131,31 @@ def layer_case(name, bits, qtype, per_channel, M=96, K=128, N=192, r=16, alpha=1
     print(f"  {name}: ok  y rms={float(out['y_x2'].pow(2).mean().sqrt()):.4f}")
 
 
+def grad_case(name, bits, qtype, per_channel, M=64, K=96, N=128, r=16, alpha=32, seed=0):
+    """Backward of the reference module (base weight frozen as in main_sp.py:83; alpha/rank = 2): grads w.r.t. the input
+    and the LoRA factors for a seeded upstream gradient."""
+    W, bias, A, B, x0, x1 = O.make_workload(M, K, N, r, seed=seed, batch=2)
+    m = ref_layer(K, N, bits, qtype, per_channel, r, alpha, W, bias, A, B)
+    ref_calibrate(m, bits, [x0, x1])
+    m.linear.weight.requires_grad_(False); m.linear.bias.requires_grad_(False)
+    lo = m.lora_adapters[f"{bits}bit"]
+    g = torch.randn(2, M // 2, N, generator=torch.Generator().manual_seed(seed + 77)) * (3.0 if qtype == "log" else 1.0)
+    xg = (x0 * 1.1).clone().requires_grad_(True)
+    with torch.enable_grad():
+        y = m(xg)
+        y.backward(g)
+    out = {"W": W, "bias": bias, "A": A, "B": B, "x0": x0, "x1": x1, "xg": xg.detach(), "g": g, "y": y.detach(),
+           "grad_x": xg.grad.clone(), "grad_A": lo.lora_A.grad.clone(), "grad_B": lo.lora_B.grad.clone()}
+    ol = O.build_calibrated_layer(W, bias, A, B, [x0, x1], bits, qtype, per_channel, alpha, r)
+    gx, gA, gB = O.sp_linear_backward(ol, xg.detach(), g)
+    for got, want, what in ((gx, out["grad_x"], "grad_x"), (gA, out["grad_A"], "grad_A"), (gB, out["grad_B"], "grad_B")):
+        err = float((got - want).abs().max() / want.abs().max().clamp(min=1e-30))
+        assert err < 2e-6, f"oracle backward != reference autograd at {name}.{what}: {err:.2e}"
+    meta = dict(bits=bits, qtype=qtype, per_channel=per_channel, r=r, alpha=alpha, M=M, K=K, N=N)
+    np.savez_compressed(os.path.join(HERE, f"grad_{name}.npz"), meta=json.dumps(meta), **{k: v.numpy() for k, v in out.items()})
+    print(f"  grad {name}: ok")
+
+
 def quantizer_case(name, bits, qtype, symmetric, per_channel, channel_dim, shape, seed, batches=2,
                    all_tiny_first=False):
     """Standalone LearnableFakeQuantize (covers the asymmetric branches no caller uses, multi-batch
@@ -222,6 +247,12 @@ if __name__ == "__main__":
     quantizer_case("q_mm8_sym_mid", 8, "minmax", True, True, 1, (6, 10, 12), 23, batches=3)
     quantizer_case("q_log6_tinyfirst", 6, "log", True, True, -1, (3, 8, 16), 24, all_tiny_first=True)
     quantizer_case("q_log4_pt", 4, "log", True, False, 0, (32, 24), 25)
+    with torch.enable_grad():
+        torch.set_grad_enabled(True)
+        grad_case("mm4_pc", 4, "minmax", True, seed=30)
+        grad_case("log6_pc", 6, "log", True, seed=31)
+        grad_case("mm8_pt", 8, "minmax", False, seed=32)
+        torch.set_grad_enabled(False)
     config1()
     state_dict_keys()
     print("golden fixtures written; oracle == reference bitwise on every elementwise quantity")

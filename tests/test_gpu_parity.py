@@ -258,3 +258,47 @@ def test_headline_shape_against_oracle(pkg, path):
         y_again = layer(x0.to(DEV))
     assert torch.equal(y, y_again), "forward is not deterministic"
     print(f"headline parity ({path}): max err/bound = {worst:.3f}")
+
+
+@pytest.mark.parametrize("name", ["mm4_pc", "log6_pc", "mm8_pt"])
+def test_backward_against_reference_autograd(pkg, name):
+    """fused forward + straight-through backward (autograd.Function on the MFMA kernels) against the
+    gradients the reference's autograd produced on CPU (fixtures grad_*.npz)."""
+    import json
+    import numpy as np
+    z = np.load(os.path.join(GOLDEN, f"grad_{name}.npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    t = {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+    bits, r = meta["bits"], meta["r"]
+    layer = pkg.SPLinearWithLoRA(meta["K"], meta["N"], [bits, 32], {bits: r, 32: 0}, {bits: meta["alpha"], 32: 0},
+                                 {bits: meta["qtype"], 32: None}, per_channel=meta["per_channel"])
+    key = f"{bits}bit"
+    with torch.no_grad():
+        layer.linear.weight.copy_(t["W"]); layer.linear.bias.copy_(t["bias"])
+        layer.lora_adapters[key].lora_A.copy_(t["A"]); layer.lora_adapters[key].lora_B.copy_(t["B"])
+    layer = layer.to(DEV).train()                       # training mode: operands rebuilt every call, grads on
+    layer.set_precision(bits)
+    pkg.calibrate_layer(layer, bits, [t["x0"].to(DEV), t["x1"].to(DEV)])
+    layer.linear.weight.requires_grad_(False); layer.linear.bias.requires_grad_(False)   # main_sp.py:83
+    xg = t["xg"].to(DEV).requires_grad_(True)
+    y = layer(xg)
+    assert y.grad_fn is not None and "SPLinearFunction" in type(y.grad_fn).__name__
+    tol = 1e-5 if meta["qtype"] == "minmax" else 2e-5
+    assert_close_y(y, t["y"], f"{name}.y", tol)
+    y.backward(t["g"].to(DEV))
+    lo = layer.lora_adapters[key]
+    assert_close_y(xg.grad, t["grad_x"], f"{name}.grad_x", 2e-5)
+    assert_close_y(lo.lora_A.grad, t["grad_A"], f"{name}.grad_A", 2e-5)
+    assert_close_y(lo.lora_B.grad, t["grad_B"], f"{name}.grad_B", 2e-5)
+    assert layer.linear.weight.grad is None
+    # trainable base weight + bias: straight-through d/dW = g^T . FQ(x), d/db = sum g
+    layer.linear.weight.requires_grad_(True); layer.linear.bias.requires_grad_(True)
+    xg2 = t["xg"].to(DEV).requires_grad_(True)
+    layer(xg2).backward(t["g"].to(DEV))
+    with torch.no_grad():
+        xq = layer.quantizers_input[key](t["xg"].to(DEV)).reshape(-1, meta["K"])
+        gW = t["g"].to(DEV).reshape(-1, meta["N"]).t() @ xq
+        if meta["qtype"] == "log":
+            gW = gW.clamp(-10, 10)
+    assert torch.allclose(layer.linear.weight.grad, gW, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(layer.linear.bias.grad, t["g"].to(DEV).reshape(-1, meta["N"]).sum(0), rtol=1e-4, atol=1e-4)

@@ -75,3 +75,26 @@ def test_uncalibrated_raises():
     q = O.QuantState(8)
     with pytest.raises(RuntimeError):
         q(torch.ones(3))
+
+
+GRAD_CASES = ["mm4_pc", "log6_pc", "mm8_pt"]
+
+
+def load_grad_case(name):
+    import numpy as np
+    z = np.load(os.path.join(GOLDEN, f"grad_{name}.npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return meta, {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+
+
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_backward_closed_form_matches_reference_autograd(name):
+    """The straight-through backward (quantization_methods.py:25-28, 82-90) restated in closed form against the grads
+    the reference's autograd produced (fixtures from make_golden.py)."""
+    meta, t = load_grad_case(name)
+    ol = O.build_calibrated_layer(t["W"], t["bias"], t["A"], t["B"], [t["x0"], t["x1"]], meta["bits"], meta["qtype"],
+                                  meta["per_channel"], meta["alpha"], meta["r"])
+    assert_close_y(ol.forward(t["xg"]), t["y"], "y")
+    gx, gA, gB = O.sp_linear_backward(ol, t["xg"], t["g"])
+    for got, want, what in ((gx, t["grad_x"], "grad_x"), (gA, t["grad_A"], "grad_A"), (gB, t["grad_B"], "grad_B")):
+        assert_close_y(got, want, f"{name}.{what}", 1e-5)
