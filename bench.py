@@ -187,7 +187,7 @@ def main():
             "algorithmic_GBps_per_gpu": round(BYTES_PER_STEP * args.steps / elapsed / 1e9, 1),
             "frac_of_hbm_peak": round(BYTES_PER_STEP * args.steps / elapsed / 1e9 / PEAK["hbm_gbs"], 4),
             "calibration": {"ms": round(calib_ms, 2), "allreduce_elements": exchanged},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f16x2 (dense contraction + LoRA-up + bias)" if is_f16
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16x2_s16 (dense contraction + LoRA-up + bias, v_mfma_f32_16x16x32_f16)" if is_f16
                          else "gemm_f32_nt (dense contraction + LoRA-up + bias)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,

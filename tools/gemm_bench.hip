@@ -73,6 +73,22 @@ int main(int argc, char** argv) {
          clock_of([&] { run<16 + 12>(g, 20); }));
   printf("2x MFMA per stage: mfma-only %.1f | loads+mfma %.1f us\n", run<32 + 13>(g, 30), run<32 + 12>(g, 30));
   printf("no barriers at all: mfma-only %.1f | loads-only %.1f | loads+mfma %.1f us\n", run<64 + 13>(g, 30), run<64 + 2 + 4>(g, 30), run<64 + 12>(g, 30));
+  {
+    hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int rep = 0; rep < 2; ++rep) {
+      float ms[2];
+      for (int v = 0; v < 2; ++v) {
+        for (int i = 0; i < 5; ++i) { if (v == 0) gemm_f16x2_s16_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g); else gemm_f16x2_s16_kernel<5><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g); }
+        hipEventRecord(a);
+        for (int i = 0; i < 50; ++i) { if (v == 0) gemm_f16x2_s16_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g); else gemm_f16x2_s16_kernel<5><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g); }
+        hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms[v], a, b);
+      }
+      printf("16x16x32 variant: full %.1f | no-loads,no-stores %.1f us\n", ms[0] / 50 * 1e3f, ms[1] / 50 * 1e3f);
+    }
+  }
   const int iters = 50;
   for (int rep = 0; rep < 2; ++rep) {
     printf("full %.1f | no-loads %.1f | no-compute %.1f | no-stores %.1f | no-loads,no-stores %.1f | mfma-only %.1f | stores-only %.1f | loads+mfma(no frag reads, no stores) %.1f us\n",

@@ -1,0 +1,18 @@
+"""Kernel-time probe for the log-quantised (F32-path) forward: run under rocprofv3 --kernel-trace."""
+import sys, torch
+sys.path.insert(0, '/root/repo')
+import llm_qat_on_gpt2_amd as pkg
+from oracle import ref_cpu as O
+dev = 'cuda:0'
+M, K, N, r, bits = 8192, 1024, 4096, 64, 6          # BASELINE configs[4]: GPT-2-medium c_fc, log 6-bit
+W, bias, A, B, x0, x1 = O.make_workload(M, K, N, r, seed=0, batch=8)
+layer = pkg.SPLinearWithLoRA(K, N, [bits, 32], {bits: r, 32: 0}, {bits: 64, 32: 0}, {bits: 'log', 32: None})
+with torch.no_grad():
+    layer.linear.weight.copy_(W); layer.linear.bias.copy_(bias)
+    layer.lora_adapters['6bit'].lora_A.copy_(A); layer.lora_adapters['6bit'].lora_B.copy_(B)
+layer = layer.to(dev).eval(); layer.set_precision(bits)
+pkg.calibrate_layer(layer, bits, [x0.to(dev), x1.to(dev)])
+x = x0.to(dev)
+with torch.no_grad():
+    for _ in range(20): layer(x)
+    torch.cuda.synchronize()
