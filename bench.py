@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--path", choices=["auto", "f32", "f16x2", "u8x2"], default="auto")
+    ap.add_argument("--path", choices=["auto", "f32", "f16x2", "u8x2", "f16x3"], default="auto")
     ap.add_argument("--hoist-weights", action="store_true",
                     help="reuse prepared weight operands across steps (eval-mode behaviour of the module)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,7 +121,7 @@ def main():
         layer.lora_adapters[key].lora_A.copy_(A); layer.lora_adapters[key].lora_B.copy_(B)
     layer = layer.to(dev).eval()
     layer.set_precision(BITS)
-    layer.operand_path = {"auto": pkg._lib.PATH_AUTO, "f32": pkg._lib.PATH_F32, "f16x2": pkg._lib.PATH_F16X2, "u8x2": pkg._lib.PATH_U8X2}[args.path]
+    layer.operand_path = {"auto": pkg._lib.PATH_AUTO, "f32": pkg._lib.PATH_F32, "f16x2": pkg._lib.PATH_F16X2, "u8x2": pkg._lib.PATH_U8X2, "f16x3": pkg._lib.PATH_F16X3}[args.path]
     layer.cache_operands = bool(args.hoist_weights)
 
     # calibration: 2 local batches per rank, then ONE all-reduce(MAX) of [-min | max] (RCCL) -> identical scales
@@ -186,7 +186,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * FLOP_PER_STEP * args.steps / elapsed / 1e9
         gemm_avg_ms = sum(gemm_ms) / max(1, len(gemm_ms))
-        is_f16 = path_used in (pkg._lib.PATH_F16X2, pkg._lib.PATH_U8X2)
+        is_f16 = path_used in (pkg._lib.PATH_F16X2, pkg._lib.PATH_U8X2, pkg._lib.PATH_F16X3)
         achieved = FLOP_PER_STEP / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms > 0 else 0.0
         peak = PEAK["f16"] if is_f16 else PEAK["f32"]
         traffic = None
@@ -205,7 +205,7 @@ def main():
             "config": {"workload": "SPLinearWithLoRA c_fc 768->3072, 4-bit minmax per-channel + LoRA r=64, "
                                    "batch 8 x seq 1024 = 8192 tokens per GPU (SURVEY.md 8d headline)",
                        "tokens_per_gpu": M_TOKENS, "parallelism": f"dp{world} (replicas over the batch)",
-                       "operand_path": {1: "f32", 2: "f16x2", 3: "u8x2"}[path_used], "weights_requantized_every_step": not args.hoist_weights,
+                       "operand_path": {1: "f32", 2: "f16x2", 3: "u8x2", 4: "f16x3"}[path_used], "weights_requantized_every_step": not args.hoist_weights,
                        "flop_per_step_per_gpu": FLOP_PER_STEP, "algorithmic_bytes_per_step_per_gpu": BYTES_PER_STEP},
             "value_per_gpu": round(value / world, 1),
             "algorithmic_GBps_per_gpu": round(BYTES_PER_STEP * args.steps / elapsed / 1e9, 1),

@@ -43,7 +43,9 @@ enum spq_path {
   SPQ_PATH_AUTO = 0,
   SPQ_PATH_F32 = 1,   /* fp32-input MFMA on dequantised fp32 operands: always valid */
   SPQ_PATH_F16X2 = 2, /* exact integer levels (fp16) x 2-limb fp16 weights on f16 MFMA: minmax, symmetric, bits<=12 */
-  SPQ_PATH_U8X2 = 3   /* same arithmetic, levels stored as bytes (bits<=8), 3-slot LDS ring; same prepared operands as F16X2 */
+  SPQ_PATH_U8X2 = 3,  /* same arithmetic, levels stored as bytes (bits<=8), 3-slot LDS ring; same prepared operands as F16X2 */
+  SPQ_PATH_F16X3 = 4  /* any input quantizer (log, asymmetric, >12 bit): FQ(x)*2^G as two fp16 limbs x 2-limb weights, three
+                         f16 MFMA products per algorithmic product; operands prepared with sx = 1 (no scale folding) */
 };
 
 typedef void* spq_stream_t;
@@ -123,6 +125,7 @@ typedef struct spq_fwd_args {
   const float* x;              /* [M, K] */
   const float* sx;             /* input scale (log: range) */
   const float* zx;             /* input zero point (log: min) */
+  const float* x_limb_scale;   /* F16X3 only: device {2^G, 2^-G}, 2^G * (bound of |FQ(x)|) in [2^13, 2^14) */
   /* prepared operands (spq_prepare_*) */
   const void* w_prep;          /* F32: fp32 FQ(W) [N,K];  F16X2: hi/lo limb planes */
   const float* w_rowscale;     /* F16X2: per-row power-of-two descale [N]; else NULL */

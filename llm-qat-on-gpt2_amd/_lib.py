@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspq.so")
 
 MINMAX, LOG = 0, 1
-PATH_AUTO, PATH_F32, PATH_F16X2, PATH_U8X2 = 0, 1, 2, 3
+PATH_AUTO, PATH_F32, PATH_F16X2, PATH_U8X2, PATH_F16X3 = 0, 1, 2, 3, 4
 QTYPE_CODE = {"minmax": MINMAX, "log": LOG}
 
 _lib = None
@@ -28,7 +28,7 @@ class FwdArgs(C.Structure):
     _fields_ = [("M", _i64), ("K", _i64), ("N", _i64), ("r", _i64),
                 ("bits", _int), ("qtype", _int), ("symmetric", _int), ("quantize_input", _int),
                 ("x_per_channel", _int), ("path", _int),
-                ("x", _p), ("sx", _p), ("zx", _p),
+                ("x", _p), ("sx", _p), ("zx", _p), ("x_limb_scale", _p),
                 ("w_prep", _p), ("w_rowscale", _p), ("bias", _p), ("a_prep", _p), ("b_prep", _p),
                 ("lora_scaling", _f),
                 ("y", _p), ("workspace", _p), ("workspace_bytes", _sz),

@@ -40,7 +40,7 @@ constexpr int XR = 32, XK = 64;                // activation-pass tile: rows per
 
 struct F16x2Layout {                            // workspace carve-up, all offsets 256-B aligned
   int64_t Mp, Kp, Rp;
-  size_t off_qx, off_thi, off_tlo, off_rowinv, total;
+  size_t off_qx, off_xl, off_thi, off_tlo, off_rowinv, total;
 };
 
 static F16x2Layout make_layout(int64_t M, int64_t K, int64_t r) {
@@ -48,6 +48,7 @@ static F16x2Layout make_layout(int64_t M, int64_t K, int64_t r) {
   L.Mp = pad_to(M, GM); L.Kp = pad_to(K, GK); L.Rp = r > 0 ? pad_to(r, GK) : 0;
   size_t o = 0;
   L.off_qx = o; o += pad_to((size_t)L.Mp * L.Kp * 2, 256);
+  L.off_xl = o; o += pad_to((size_t)L.Mp * L.Kp * 2, 256);      // lo limb of FQ(x), SPQ_PATH_F16X3 only
   L.off_thi = o; o += pad_to((size_t)L.Mp * L.Rp * 2, 256);
   L.off_tlo = o; o += pad_to((size_t)L.Mp * L.Rp * 2, 256);
   L.off_rowinv = o; o += pad_to((size_t)L.Mp * 4, 256);
@@ -213,6 +214,10 @@ struct XPassArgs {
   int M, K, r, Kp, Rp;
   int x_pc, bits;
   int a8;                                   // 1: levels are written as bytes q + 128 (bits <= 8), else as fp16
+  // limbs != 0 (SPQ_PATH_F16X3): any input quantizer; FQ(x) * xscale[0] is written as two fp16 limbs (qx = hi, xl = lo)
+  int limbs, qtype, symmetric;
+  _Float16* xl;
+  const float* xscale;                      // device {2^G, 2^-G}: power of two that puts the quantizer's range bound at 2^14
 };
 
 // One WAVE per output row (4 rows per workgroup): the row's FQ(W) values stay in registers between the max pass and
@@ -362,6 +367,34 @@ __device__ __forceinline__ void xpass_finish(const XPassArgs& a, const f32x16 (&
   }
 }
 
+// activation operand of four consecutive elements at element index idx: exact integer levels (fp16, or bytes q + 128
+// when a8) for the symmetric-minmax path, or the two fp16 limbs of FQ(x) * 2^G for any other input quantizer
+__device__ __forceinline__ void store_act4(const XPassArgs& a, int64_t idx, float4 v, float4 sc, float4 zp, float qlo, float qhi,
+                                           float pscale) {
+  if (a.limbs) {
+    const float f0 = fq_dispatch(v.x, sc.x, zp.x, a.bits, a.qtype, a.symmetric) * pscale;     // * 2^G exact
+    const float f1 = fq_dispatch(v.y, sc.y, zp.y, a.bits, a.qtype, a.symmetric) * pscale;
+    const float f2 = fq_dispatch(v.z, sc.z, zp.z, a.bits, a.qtype, a.symmetric) * pscale;
+    const float f3 = fq_dispatch(v.w, sc.w, zp.w, a.bits, a.qtype, a.symmetric) * pscale;
+    union { _Float16 h[4]; uint2 u; } hi, lo;
+    split2(f0, hi.h[0], lo.h[0]); split2(f1, hi.h[1], lo.h[1]); split2(f2, hi.h[2], lo.h[2]); split2(f3, hi.h[3], lo.h[3]);
+    *reinterpret_cast<uint2*>(a.qx + idx) = hi.u;
+    *reinterpret_cast<uint2*>(a.xl + idx) = lo.u;
+    return;
+  }
+  const float q0 = minmax_level<true>(v.x, sc.x, 0.f, qlo, qhi), q1 = minmax_level<true>(v.y, sc.y, 0.f, qlo, qhi);
+  const float q2 = minmax_level<true>(v.z, sc.z, 0.f, qlo, qhi), q3 = minmax_level<true>(v.w, sc.w, 0.f, qlo, qhi);
+  if (a.a8) {
+    const unsigned u = (unsigned)((int)q0 + 128) | ((unsigned)((int)q1 + 128) << 8) | ((unsigned)((int)q2 + 128) << 16) |
+                       ((unsigned)((int)q3 + 128) << 24);
+    *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(a.qx) + idx) = u;
+  } else {
+    union { _Float16 hh[4]; uint2 u; } q;
+    q.hh[0] = (_Float16)q0; q.hh[1] = (_Float16)q1; q.hh[2] = (_Float16)q2; q.hh[3] = (_Float16)q3;
+    *reinterpret_cast<uint2*>(a.qx + idx) = q.u;
+  }
+}
+
 // four consecutive integer levels -> level matrix at element index idx (fp16, or bytes q + 128 when a8)
 __device__ __forceinline__ void store_levels4(_Float16* qx, int64_t idx, float q0, float q1, float q2, float q3, int a8) {
   if (a8) {
@@ -452,10 +485,24 @@ __global__ __launch_bounds__(256) void xpass_kernel(XPassArgs a) {
         s0 = (k + 0 < a.K) ? a.sx[k + 0] : 1.f; s1 = (k + 1 < a.K) ? a.sx[k + 1] : 1.f;
         s2 = (k + 2 < a.K) ? a.sx[k + 2] : 1.f; s3 = (k + 3 < a.K) ? a.sx[k + 3] : 1.f;
       } else { s0 = s1 = s2 = s3 = a.sx[0]; }
-      if (m < a.M)                                                                   // k < Kp always; pad k -> level 0
-        store_levels4(a.qx, (int64_t)m * a.Kp + k, minmax_level<true>(v.x, s0, 0.f, qlo, qhi),
-                      minmax_level<true>(v.y, s1, 0.f, qlo, qhi), minmax_level<true>(v.z, s2, 0.f, qlo, qhi),
-                      minmax_level<true>(v.w, s3, 0.f, qlo, qhi), a.a8);
+      if (m < a.M) {                                                                 // k < Kp always; pad k -> level 0
+        float4 zp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.limbs) {
+          if (a.x_pc) {
+            zp4.x = (k + 0 < a.K) ? a.zx[k + 0] : 0.f; zp4.y = (k + 1 < a.K) ? a.zx[k + 1] : 0.f;
+            zp4.z = (k + 2 < a.K) ? a.zx[k + 2] : 0.f; zp4.w = (k + 3 < a.K) ? a.zx[k + 3] : 0.f;
+          } else { const float z1 = a.zx[0]; zp4 = make_float4(z1, z1, z1, z1); }
+        }
+        float4 vv = v;
+        if (a.limbs) {                                                               // pad columns must come out as zero limbs
+          if (k + 0 >= a.K) vv.x = 0.f; if (k + 1 >= a.K) vv.y = 0.f; if (k + 2 >= a.K) vv.z = 0.f; if (k + 3 >= a.K) vv.w = 0.f;
+        }
+        store_act4(a, (int64_t)m * a.Kp + k, vv, make_float4(s0, s1, s2, s3), zp4, qlo, qhi, a.limbs ? a.xscale[0] : 1.f);
+        if (a.limbs && k + 3 >= a.K) {                                               // FQ(0) need not be 0 (asymmetric / log): force pads
+          _Float16* ph = a.qx + (int64_t)m * a.Kp + k; _Float16* pl = a.xl + (int64_t)m * a.Kp + k;
+          for (int j = 0; j < 4; ++j) if (k + j >= a.K) { ph[j] = (_Float16)0.f; pl[j] = (_Float16)0.f; }
+        }
+      }
     }
     if (with_lora) {
 #pragma unroll
@@ -499,7 +546,7 @@ __global__ __launch_bounds__(256) void xpass_kernel(XPassArgs a) {
 constexpr int XP_CHUNKS = 12;                              // panel = 12 chunks x 64 columns
 constexpr int XP_XS = XP_CHUNKS * XR * 64 * 4;             // 96 KB
 constexpr int XP_AS = 64 * 64 * 4;                         // 16 KB per FQ(A)^T chunk (64 rows of r)
-constexpr int XP_SX = XP_CHUNKS * 64 * 4;                  // 3 KB: the panel's input scales
+constexpr int XP_SX = 2 * XP_CHUNKS * 64 * 4;              // 6 KB: the panel's input scales and zero points
 constexpr int XP_NAS = 2;                                  // FQ(A)^T chunk buffers
 constexpr int XP_LDS = XP_XS + XP_NAS * XP_AS + XP_SX;     // 131 KB
 
@@ -512,6 +559,7 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // 8 waves: two per SIMD, so one's VALU runs under the other's MFMAs
   const int m0 = blockIdx.x * XR;
   const float qhi = (float)((1 << (a.bits - 1)) - 1), qlo = -qhi;
+  const float pscale = a.limbs ? a.xscale[0] : 1.f;
   const bool with_lora = a.r > 0;
   const int l31 = lane & 31, h = lane >> 5;
 
@@ -558,7 +606,10 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
   for (int p0 = 0; p0 < a.K; p0 += XP_CHUNKS * 64) {
     const int nch = min(XP_CHUNKS, (a.K - p0) / 64);
     for (int c = 0; c < nch; ++c) glds16(x_src + p0 + c * 64, xs + c * (XR * 256) + w * 1024);
-    for (int k = tid; k < nch * 64; k += 512) sxs[k] = a.x_pc ? a.sx[p0 + k] : a.sx[0];
+    for (int k = tid; k < nch * 64; k += 512) {
+      sxs[k] = a.x_pc ? a.sx[p0 + k] : a.sx[0];
+      sxs[XP_CHUNKS * 64 + k] = a.limbs ? (a.x_pc ? a.zx[p0 + k] : a.zx[0]) : 0.f;
+    }
     if (with_lora && p0 == 0) SPQ_STORE_A(0);
     __syncthreads();                                       // vmcnt(0): the panel landed; FQ(A)^T chunk gc is in LDS
     for (int c = 0; c < nch; ++c, ++gc) {
@@ -569,8 +620,8 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
       {
         const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + q_row * 256 + q_pos * 16);
         const float4 sc = *reinterpret_cast<const float4*>(sxs + c * 64 + q_kof);
-        store_levels4(a.qx, q_dst + k0, minmax_level<true>(v.x, sc.x, 0.f, qlo, qhi), minmax_level<true>(v.y, sc.y, 0.f, qlo, qhi),
-                      minmax_level<true>(v.z, sc.z, 0.f, qlo, qhi), minmax_level<true>(v.w, sc.w, 0.f, qlo, qhi), a.a8);
+        const float4 zp = *reinterpret_cast<const float4*>(sxs + XP_CHUNKS * 64 + c * 64 + q_kof);
+        store_act4(a, q_dst + k0, v, sc, zp, qlo, qhi, pscale);
       }
       // ---- t += x . FQ(A): wave w owns k in [8w, 8w+8) of the chunk, lane half h the 4 contiguous k 8w+4h..+3
       if (with_lora) {
@@ -610,6 +661,11 @@ struct GemmF16Args {
   int M, N, Kp, Rp;                         // Rp = 0: no LoRA
   int tiles_m, tiles_n;
   unsigned long long* dbg;                  // tools/gemm_bench only (DIAG & 16): per-workgroup clock stamps
+  // SPQ_PATH_F16X3 (gemm_f16x2_s16_kernel only): the activation operand has two limbs (qx = hi, xl = lo) scaled by
+  // xscale[0] = 2^G; per 64-deep k block the stages are (hi x {Whi,Wlo}) then (lo x {Whi})
+  const _Float16* xl;
+  const float* xscale;                      // device {2^G, 2^-G}; null when a_limbs == 1
+  int a_limbs;
 };
 
 // ---- LDS: two 64-deep stage buffers (A 256x64 f16 = 32 KB, B hi/lo 128x64 f16 = 16 KB each) + a dedicated
@@ -863,7 +919,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
 
   const int nwg = g.tiles_m * g.tiles_n;
   const int nl = (g.Rp / GK) * 2;           // LoRA stages per tile
-  const int T = nl + g.Kp / GK;             // stages per tile
+  const int al = g.a_limbs;                 // 1: integer levels; 2: two limbs of FQ(x) * 2^G
+  const int T = nl + al * (g.Kp / GK);      // stages per tile
   const int gstride = (int)gridDim.x;
 
   // XCD-aware tile order (speed only): positions of one XCD (p % 8, observed round-robin placement) map to a
@@ -880,6 +937,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
     bn = (in_band / band_rows) * GN;
   };
 
+  const float lora_to_base = (al == 2) ? g.xscale[0] : 1.f;   // LoRA partial sums carry 2^e[n]; base sums 2^(e[n]+G)
+  const float out_scale = (al == 2) ? g.xscale[1] : 1.f;
   int p = blockIdx.x;
   if (p >= nwg) return;
   int bm, bn;
@@ -901,8 +960,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
     if (t < nl) {
       const int which = t & 1;
       A = which ? g.tlo : g.thi; lda = g.Rp; Bh = g.Bhi; Bl = g.Blo; ldb = g.Rp; k0 = (t >> 1) * GK; two = !which;
-    } else {
+    } else if (al == 1) {
       A = g.qx; lda = g.Kp; Bh = g.Whi; Bl = g.Wlo; ldb = g.Kp; k0 = (t - nl) * GK; two = true;
+    } else {
+      const int tb = t - nl, which = tb & 1;
+      A = which ? g.xl : g.qx; lda = g.Kp; Bh = g.Whi; Bl = g.Wlo; ldb = g.Kp; k0 = (tb >> 1) * GK; two = !which;
     }
     const _Float16* Ab = A + (int64_t)tbm * lda + k0;          // wave-uniform base, 32-bit per-lane offsets
 #pragma unroll
@@ -981,6 +1043,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
       ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
       if (n < g.N) {
         ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);
+        ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale;   // exact
         if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
       }
     }
@@ -996,14 +1059,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                      // C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + e
-          const float ri = g.rowinv[bm + wm * 64 + tm * 16 + 4 * q4 + e];
+          const float ri = g.rowinv[bm + wm * 64 + tm * 16 + 4 * q4 + e] * lora_to_base;
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn) acc[tm][tn][e] *= ri;
         }
     }
     for (int t = nl; t < T; ++t) {
       const bool last = (t + 1 == T);
-      stage((base + t) & 1, true, !last || more, last ? 0 : t + 1, last ? nbm : bm, last ? nbn : bn);
+      const bool two = (al == 1) || !((t - nl) & 1);
+      stage((base + t) & 1, two, !last || more, last ? 0 : t + 1, last ? nbm : bm, last ? nbn : bn);
     }
 
     // ---- epilogue: y = acc * 2^-e[n] + bias[n].  Each wave transposes 16 rows x 32 cols at a time through its
@@ -1403,7 +1467,13 @@ unsigned gemm_grid(int ntiles) {
 }
 
 int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
-  if (!(a->quantize_input && a->qtype == SPQ_MINMAX && a->symmetric && a->bits >= 2 && a->bits <= 12)) {
+  const bool x3 = a->path == SPQ_PATH_F16X3;
+  if (x3) {
+    if (!(a->quantize_input && a->bits >= 1 && a->bits <= 16 && a->x_limb_scale)) {
+      set_error("spq_linear_lora_fwd: SPQ_PATH_F16X3 needs a calibrated input quantizer (1..16 bits) and x_limb_scale");
+      return SPQ_ERR_UNSUPPORTED;
+    }
+  } else if (!(a->quantize_input && a->qtype == SPQ_MINMAX && a->symmetric && a->bits >= 2 && a->bits <= 12)) {
     set_error("spq_linear_lora_fwd: SPQ_PATH_F16X2 needs a symmetric minmax input quantizer with 2..12 bits "
               "(got qtype=%d symmetric=%d bits=%d quantize_input=%d)", a->qtype, a->symmetric, a->bits, a->quantize_input);
     return SPQ_ERR_UNSUPPORTED;
@@ -1424,11 +1494,13 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   x.rowinv = (float*)(ws + L.off_rowinv);
   x.M = (int)a->M; x.K = (int)a->K; x.r = (int)a->r; x.Kp = (int)L.Kp; x.Rp = (int)L.Rp;
   x.x_pc = a->x_per_channel; x.bits = a->bits;
+  x.limbs = x3 ? 1 : 0; x.qtype = a->qtype; x.symmetric = a->symmetric;
+  x.xl = (_Float16*)(ws + L.off_xl); x.xscale = a->x_limb_scale;
   if (a->path == SPQ_PATH_U8X2 && a->bits > 8) {
     set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 needs an input quantizer of at most 8 bits (got %d)", a->bits);
     return SPQ_ERR_UNSUPPORTED;
   }
-  const bool a8 = a->path == SPQ_PATH_U8X2;   // levels as bytes + 3-slot ring kernel (opt-in: measured 5 %% slower)
+  const bool a8 = a->path == SPQ_PATH_U8X2;   // levels as bytes + 3-slot ring kernel (opt-in)
   x.a8 = a8 ? 1 : 0;
   const unsigned xgrid = (unsigned)((a->M + XR - 1) / XR);
   const bool panel_ok = (a->K % 64 == 0) && L.Rp <= 64 && aligned16(a->x) && (a->r == 0 || aligned16(a->a_prep)) &&
@@ -1472,6 +1544,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   g.rowinv = x.rowinv; g.rowscale = a->w_rowscale; g.bias = a->bias; g.y = a->y;
   g.M = (int)a->M; g.N = (int)a->N; g.Kp = (int)L.Kp; g.Rp = (int)L.Rp;
   g.tiles_m = (int)(L.Mp / GM); g.tiles_n = (int)(P.Np / GN); g.dbg = nullptr;
+  g.xl = x.xl; g.xscale = a->x_limb_scale; g.a_limbs = x3 ? 2 : 1;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_f16x2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1488,6 +1561,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     mfma16 = (e && e[0] == '0') ? 0 : 1;
     if (mfma16) (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
   }
+  if (x3 && !mfma16) { set_error("spq_linear_lora_fwd: SPQ_PATH_F16X3 needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
   if (mfma16) gemm_f16x2_s16_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS, st>>>(g);
   else gemm_f16x2_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS, st>>>(g);
   if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);

@@ -76,11 +76,11 @@ def _gemm_nt(a, b_nk, bias=None):
 
 class _Prepared:
     """Weight-side GEMM operands of one bit-width plus the signature of what they were built from."""
-    __slots__ = ("sig", "path", "w", "w_rowscale", "a", "b", "r")
+    __slots__ = ("sig", "path", "w", "w_rowscale", "a", "b", "r", "x_limb_scale")
 
     def __init__(self):
         self.sig = None
-        self.w = self.w_rowscale = self.a = self.b = None
+        self.w = self.w_rowscale = self.a = self.b = self.x_limb_scale = None
         self.r = 0
 
 
@@ -228,7 +228,8 @@ class SPLinearWithLoRA(nn.Module):
             M=M, K=K, N=N, r=r, bits=int(qx.num_bits), qtype=_lib.QTYPE_CODE.get(qx.quantizer_type, 0),
             symmetric=1 if qx.symmetric else 0, quantize_input=quantize_input,
             x_per_channel=1 if (quantize_input and sx.numel() > 1) else 0, path=prep.path,
-            x=x2.data_ptr(), sx=_lib.ptr(sx), zx=_lib.ptr(zx), w_prep=prep.w.data_ptr(),
+            x=x2.data_ptr(), sx=_lib.ptr(sx), zx=_lib.ptr(zx), x_limb_scale=_lib.ptr(prep.x_limb_scale),
+            w_prep=prep.w.data_ptr(),
             w_rowscale=_lib.ptr(prep.w_rowscale), bias=_lib.ptr(bias), a_prep=_lib.ptr(prep.a) if r else None,
             b_prep=_lib.ptr(prep.b) if r else None, lora_scaling=float(lora.scaling) if r else 0.0,
             y=y.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
@@ -243,10 +244,16 @@ class SPLinearWithLoRA(nn.Module):
     def _choose_path(self, qx, qw, lora, use_lora, quantize_input):
         """SPQ_PATH_F16X2 (exact integer levels x 2-limb fp16 weights) whenever the input quantizer allows it:
         symmetric minmax, <= 12 bits, actually quantising; otherwise the always-valid fp32-MFMA path."""
+        shape_ok = (not use_lora or lora.rank <= 128) and self.out_features % 4 == 0
         f16_ok = (quantize_input and qx.quantizer_type == 'minmax' and qx.symmetric and 2 <= qx.num_bits <= 12
-                  and (not use_lora or lora.rank <= 128))
+                  and shape_ok)
+        # any other calibrated input quantizer (log, asymmetric, > 12 bit): FQ(x) as two fp16 limbs
+        x3_ok = (quantize_input and not f16_ok and qx.quantizer_type in _lib.QTYPE_CODE and 1 <= qx.num_bits <= 16
+                 and shape_ok)
         if self.operand_path == _lib.PATH_AUTO:
-            return _lib.PATH_F16X2 if f16_ok else _lib.PATH_F32
+            return _lib.PATH_F16X2 if f16_ok else (_lib.PATH_F16X3 if x3_ok else _lib.PATH_F32)
+        if self.operand_path == _lib.PATH_F16X3:
+            return _lib.PATH_F16X3 if (x3_ok or f16_ok) else _lib.PATH_F32
         if self.operand_path in (_lib.PATH_F16X2, _lib.PATH_U8X2) and not f16_ok:
             return _lib.PATH_F32            # e.g. calibration forwards (raw x) of a layer pinned to F16X2
         if self.operand_path == _lib.PATH_U8X2 and qx.num_bits > 8:
@@ -268,8 +275,8 @@ class SPLinearWithLoRA(nn.Module):
         W = self.linear.weight
         path = self._choose_path(qx, qw, lora, use_lora, quantize_input)
         sig = [path, use_lora, _sig(W), qw._epoch, _sig(qw.scale), _sig(qw.zero_point)]
-        if path in (_lib.PATH_F16X2, _lib.PATH_U8X2):
-            sig += [qx._epoch, _sig(qx.scale)]
+        if path in (_lib.PATH_F16X2, _lib.PATH_U8X2, _lib.PATH_F16X3):
+            sig += [qx._epoch, _sig(qx.scale), _sig(qx.zero_point)]
         if use_lora:
             for q, t in ((lora.quantize_A, lora.lora_A), (lora.quantize_B, lora.lora_B)):
                 if not q.calibrated:
@@ -318,6 +325,14 @@ class SPLinearWithLoRA(nn.Module):
         for q, n_expected, what in ((qw, N, "weight"), (qb, N, "LoRA-B")):
             if q is not None and q.scale.numel() not in (1, n_expected):
                 raise RuntimeError(f"{what} scale of shape {tuple(q.scale.shape)} does not fit {n_expected} output features")
+        if prep.path == _lib.PATH_F16X3:
+            # no scale folding: the activation operand is FQ(x) itself, as two limbs of FQ(x) * 2^G (G from the quantizer's
+            # own range bound -- FQ clamps, so the bound holds for any input); everything stays on the device
+            sx_t = _ones(W.device)
+            prep.x_limb_scale = _limb_scale(qx)
+        else:
+            sx_t = qx.scale
+            prep.x_limb_scale = None
         with torch.cuda.device(W.device):
             rc = lib.spq_prepare_f16x2(
                 W.data_ptr(), N, K, qw.scale.data_ptr(), qw.zero_point.data_ptr(), 1 if qw.scale.numel() > 1 else 0,
@@ -329,11 +344,38 @@ class SPLinearWithLoRA(nn.Module):
                 _lib.ptr(A), _lib.ptr(qa.scale) if qa else None, _lib.ptr(qa.zero_point) if qa else None,
                 (1 if qa.scale.numel() > 1 else 0) if qa else 0, int(qa.num_bits) if qa else 0,
                 _lib.QTYPE_CODE[qa.quantizer_type] if qa else 0, (1 if qa.symmetric else 0) if qa else 1,
-                qx.scale.data_ptr(), 1 if qx.scale.numel() > 1 else 0,
+                sx_t.data_ptr(), 1 if sx_t.numel() > 1 else 0,
                 prep.w.data_ptr(), prep.w.numel(), prep.w_rowscale.data_ptr(), _lib.ptr(prep.a) if use_lora else None,
                 _lib.stream_ptr(W.device))
         _lib.check(rc, "spq_prepare_f16x2")
         prep.b = prep.w      # LoRA-B limbs live inside the same buffer
+
+
+_ones_cache = {}
+
+
+def _ones(device):
+    t = _ones_cache.get(device)
+    if t is None:
+        t = _ones_cache[device] = torch.ones(1, dtype=torch.float32, device=device)
+    return t
+
+
+def _limb_scale(q: LearnableFakeQuantize) -> torch.Tensor:
+    """Device tensor {2^G, 2^-G} with bound(|FQ(x)|) * 2^G in [2^13, 2^14), from the quantizer's own range:
+    minmax symmetric n*scale; asymmetric max(|0-zp|, |2^b-1-zp|)*scale; log 2^(log_min + log_range).  No host sync."""
+    s, z = q.scale.detach().float(), q.zero_point.detach().float()
+    if q.quantizer_type == 'log':
+        bound = torch.exp2((z + s.clamp(min=0)).amax())
+    elif q.symmetric:
+        bound = s.amax() * float(2 ** (q.num_bits - 1) - 1)
+    else:
+        bound = (torch.maximum(z.abs(), (float(2 ** q.num_bits - 1) - z).abs()) * s).amax()
+    bound = bound * (1.0 + 2.0 ** -10)                                  # rounding margin
+    _, e = torch.frexp(bound)                                           # bound = m * 2^e, m in [0.5, 1)
+    p = torch.ldexp(torch.ones_like(bound), 14 - e)
+    p = torch.where(torch.isfinite(p) & (bound > 0), p, torch.ones_like(p))
+    return torch.stack([p, 1.0 / p]).to(torch.float32).contiguous()
 
 
 class _SPLinearFunction(torch.autograd.Function):

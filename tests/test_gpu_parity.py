@@ -115,13 +115,14 @@ def test_quantizer_case(pkg, name):
     check_levels(q, t["xt"].to(DEV), t["fq_xt"], t["lv_xt"], meta["qtype"], name)
 
 
-@pytest.mark.parametrize("path", ["auto", "f32", "u8x2"])
+@pytest.mark.parametrize("path", ["auto", "f32", "u8x2", "f16x3"])
 @pytest.mark.parametrize("name", LAYER_CASES)
 def test_layer_case(pkg, name, path):
     meta, t = load_case(name)
-    if path != "auto" and meta["qtype"] != "minmax":
-        pytest.skip("log input quantizers always take the f32 path; covered by path=auto")
-    layer, key = build_layer(pkg, meta, t, {"auto": pkg._lib.PATH_AUTO, "f32": pkg._lib.PATH_F32, "u8x2": pkg._lib.PATH_U8X2}[path])
+    if path == "u8x2" and meta["qtype"] != "minmax":
+        pytest.skip("byte levels exist for minmax only; log cases run as auto (two-limb path), f32 and f16x3")
+    layer, key = build_layer(pkg, meta, t, {"auto": pkg._lib.PATH_AUTO, "f32": pkg._lib.PATH_F32, "u8x2": pkg._lib.PATH_U8X2,
+                                            "f16x3": pkg._lib.PATH_F16X3}[path])
     lora = layer.lora_adapters[key]
     quants = {"qx": layer.quantizers_input[key], "qw": layer.quantizers_weight[key], "qA": lora.quantize_A,
               "qB": lora.quantize_B}
@@ -160,7 +161,9 @@ def test_layer_case(pkg, name, path):
         layer.calibration_mode = False
         y2d = layer(t["x2"].reshape(-1, meta["K"])[:40].contiguous().to(DEV))
     assert tuple(y2.shape) == tuple(t["y_x2"].shape) and tuple(y2d.shape) == tuple(t["y_2d"].shape)
-    want = pkg._lib.PATH_F16X2 if (path == "auto" and qt == "minmax" and meta["bits"] <= 12) else pkg._lib.PATH_F32
+    f16_ok = qt == "minmax" and meta["bits"] <= 12
+    want = {"auto": pkg._lib.PATH_F16X2 if f16_ok else pkg._lib.PATH_F16X3, "f32": pkg._lib.PATH_F32,
+            "f16x3": pkg._lib.PATH_F16X3, "u8x2": None}[path]
     if path == "u8x2":
         want = pkg._lib.PATH_U8X2 if meta["bits"] <= 8 else (pkg._lib.PATH_F16X2 if meta["bits"] <= 12 else pkg._lib.PATH_F32)
     assert layer._last_path == want, (layer._last_path, want)

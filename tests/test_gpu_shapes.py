@@ -19,12 +19,12 @@ def pkg():
     return p
 
 
-def make_pair(pkg, M, K, N, r, bits, qtype, per_channel, seed, batch=4, alpha=None):
+def make_pair(pkg, M, K, N, r, bits, qtype, per_channel, seed, batch=4, alpha=None, symmetric=True):
     """(product layer on GPU, calibrated oracle layer, activations)"""
     from oracle import ref_cpu as O
     W, bias, A, B, x0, x1 = O.make_workload(M, K, N, r, seed=seed, batch=batch)
     alpha = r if alpha is None else alpha
-    ol = O.build_calibrated_layer(W, bias, A, B, [x0, x1], bits, qtype, per_channel, alpha, r)
+    ol = O.build_calibrated_layer(W, bias, A, B, [x0, x1], bits, qtype, per_channel, alpha, r, symmetric=symmetric)
     layer = pkg.SPLinearWithLoRA(K, N, [bits, 32], {bits: r, 32: 0}, {bits: alpha, 32: 0}, {bits: qtype, 32: None},
                                  per_channel=per_channel)
     key = f"{bits}bit"
@@ -33,6 +33,10 @@ def make_pair(pkg, M, K, N, r, bits, qtype, per_channel, seed, batch=4, alpha=No
         layer.lora_adapters[key].lora_A.copy_(A); layer.lora_adapters[key].lora_B.copy_(B)
     layer = layer.to(DEV).eval()
     layer.set_precision(bits)
+    if not symmetric:
+        for q in (layer.quantizers_input[key], layer.quantizers_weight[key], layer.lora_adapters[key].quantize_A,
+                  layer.lora_adapters[key].quantize_B):
+            q.symmetric = False
     pkg.calibrate_layer(layer, bits, [x0.to(DEV), x1.to(DEV)])
     return layer, ol, x0, x1
 
@@ -52,7 +56,8 @@ SHAPES = [
     ("rank100_K72",        300,  72,   260,  100, 4, "minmax", True),     # rank and K not multiples of 64: generic activation pass
     ("bits2",              512,  256,  256,  32, 2, "minmax", True),
     ("bits12_fp16_levels", 512,  256,  256,  32, 12, "minmax", True),     # largest width of the exact-integer path
-    ("bits13_falls_to_f32", 256, 128,  128,  16, 13, "minmax", True),
+    ("bits13_two_limbs",   256,  128,  128,  16, 13, "minmax", True),
+    ("bits16_two_limbs",   256,  128,  128,  16, 16, "minmax", False),
     ("log4_per_tensor",    512,  256,  256,  32, 4, "log",    False),
 ]
 
@@ -75,8 +80,30 @@ def test_linear_shapes_against_oracle(pkg, name, M, K, N, r, bits, qtype, pc):
     tol = 1e-5 if qtype == "minmax" else 2e-5
     assert_close_y(y, ol.forward(x1), f"{name}.y", tol)
     assert_close_y(base, ol.forward(x1, calibration_mode=True), f"{name}.base", tol)
-    want = pkg._lib.PATH_F16X2 if (qtype == "minmax" and bits <= 12) else pkg._lib.PATH_F32
+    want = pkg._lib.PATH_F16X2 if (qtype == "minmax" and bits <= 12) else pkg._lib.PATH_F16X3
     assert layer._last_path == want
+    if want == pkg._lib.PATH_F16X3:                      # the always-valid fp32 operands agree too
+        layer.operand_path = pkg._lib.PATH_F32
+        with torch.no_grad():
+            assert_close_y(layer(x1.to(DEV)), ol.forward(x1), f"{name}.y_f32", tol)
+        assert layer._last_path == pkg._lib.PATH_F32
+
+
+@pytest.mark.parametrize("qtype,bits,pc", [("minmax", 4, True), ("minmax", 8, False), ("log", 5, True)])
+def test_asymmetric_quantizers(pkg, qtype, bits, pc):
+    """quantization.py:17-20 / :50-54 asymmetric branches (the reference's layers never enable them, its quantizer class
+    does): activations go as two fp16 limbs of FQ(x); the fp32 operands agree."""
+    layer, ol, x0, x1 = make_pair(pkg, 640, 192, 320, 24, bits, qtype, pc, seed=5, symmetric=False)
+    tol = 1e-5 if qtype == "minmax" else 2e-5
+    with torch.no_grad():
+        y = layer(x1.to(DEV))
+        assert layer._last_path == pkg._lib.PATH_F16X3
+        layer.operand_path = pkg._lib.PATH_F32
+        y32 = layer(x1.to(DEV))
+        assert layer._last_path == pkg._lib.PATH_F32
+    ref = ol.forward(x1)
+    assert_close_y(y, ref, "asym.y", tol)
+    assert_close_y(y32, ref, "asym.y_f32", tol)
 
 
 def test_properties_at_headline_size(pkg):

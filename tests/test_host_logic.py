@@ -125,11 +125,13 @@ def test_operand_path_choice():
     L = pkg._lib
     assert layer._choose_path(qx4, None, layer.lora_adapters["4bit"], True, 1) == L.PATH_F16X2
     assert layer._choose_path(qx4, None, layer.lora_adapters["4bit"], True, 0) == L.PATH_F32    # calibration: raw x
-    assert layer._choose_path(qx6, None, layer.lora_adapters["6bit"], True, 1) == L.PATH_F32    # log input quantizer
+    assert layer._choose_path(qx6, None, layer.lora_adapters["6bit"], True, 1) == L.PATH_F16X3  # log input quantizer: limbs
     layer.operand_path = L.PATH_F32
     assert layer._choose_path(qx4, None, layer.lora_adapters["4bit"], True, 1) == L.PATH_F32
     layer.operand_path = L.PATH_F16X2
     assert layer._choose_path(qx6, None, layer.lora_adapters["6bit"], True, 1) == L.PATH_F32    # pinned but invalid
+    layer.operand_path = L.PATH_F32
+    assert layer._choose_path(qx6, None, layer.lora_adapters["6bit"], True, 1) == L.PATH_F32
 
 
 def test_forward_refuses_cpu_tensors_and_teacher_path_is_plain_linear():
