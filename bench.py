@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--hoist-weights", action="store_true",
                     help="reuse prepared weight operands across steps (eval-mode behaviour of the module)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--calib-comm", choices=["torch", "capi"], default="torch",
+                    help="calibration all-reduce through torch.distributed (backend nccl = RCCL) or through libspq's own "
+                         "RCCL binding (spq_comm_init / spq_allreduce_minmax)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,7 +129,10 @@ def main():
 
     # calibration: 2 local batches per rank, then ONE all-reduce(MAX) of [-min | max] (RCCL) -> identical scales
     t0 = time.perf_counter()
-    exchanged = pkg.calibrate_layer(layer, BITS, [act(), act()])
+    comm = None
+    if args.calib_comm == "capi":
+        comm = pkg.SpqComm.from_process_group() if world > 1 else pkg.SpqComm(0, 1, pkg.SpqComm.unique_id())
+    exchanged = pkg.calibrate_layer(layer, BITS, [act(), act()], comm=comm)
     torch.cuda.synchronize()
     calib_ms = (time.perf_counter() - t0) * 1e3
 
@@ -210,7 +216,7 @@ def main():
             "value_per_gpu": round(value / world, 1),
             "algorithmic_GBps_per_gpu": round(BYTES_PER_STEP * args.steps / elapsed / 1e9, 1),
             "frac_of_hbm_peak": round(BYTES_PER_STEP * args.steps / elapsed / 1e9 / PEAK["hbm_gbs"], 4),
-            "calibration": {"ms": round(calib_ms, 2), "allreduce_elements": exchanged},
+            "calibration": {"ms": round(calib_ms, 2), "allreduce_elements": exchanged, "comm": args.calib_comm},
             "with_cached_weight_operands": None if elapsed_cached is None else {
                 "ms_per_step": round(elapsed_cached / args.steps * 1e3, 4),
                 "value": round(world * FLOP_PER_STEP * args.steps / elapsed_cached / 1e9, 1),
@@ -226,6 +232,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.destroy()
     if world > 1:
         dist.destroy_process_group()
 

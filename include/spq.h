@@ -100,6 +100,24 @@ int spq_fakequant_transposed(const float* x, int64_t rows, int64_t cols, const f
                              float out_scaling, float* out_f32, spq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * The path's only exchange step: before finish_calibration every rank merges the running
+ * statistics of its input quantizers (quantization.py:202-207 across ranks) with ONE in-place
+ * all-reduce(MAX) over the flat fp32 buffer [-min_0 .. | max_0 ..] -- ncclAllReduce(ncclFloat, ncclMax) of
+ * RCCL over xGMI.  min/max are exact and associative, so the result is bit-identical to one process seeing
+ * every batch.  RCCL is bound at run time (dlopen librccl.so.1); SPQ_ERR_UNSUPPORTED if it is absent.
+ *   spq_comm_unique_id : rank 0 fills a SPQ_COMM_ID_BYTES host buffer; the caller ships it to the other
+ *                        ranks (any side channel: the torch.distributed store, MPI, a file).
+ *   spq_comm_init      : collective; binds the calling thread's current HIP device.
+ * ------------------------------------------------------------------------------------------------- */
+#define SPQ_COMM_ID_BYTES 128
+typedef void* spq_comm_t;
+int spq_comm_unique_id(void* id_out /* host, SPQ_COMM_ID_BYTES */);
+int spq_comm_init(int rank, int nranks, const void* unique_id /* host */, spq_comm_t* comm_out);
+int spq_comm_destroy(spq_comm_t comm);
+int spq_allreduce_minmax(spq_comm_t comm, float* neg_min_and_max /* device, in place */, size_t len,
+                         spq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Dense contraction on fp32-input MFMA (v_mfma_f32_32x32x2_f32), "NT" layout:
  *   C[m, n] = sum_k A[m,k] * B[n,k]  + bias[n]  + alpha2 * sum_j A2[m,j] * B2[n,j]
  * bias, A2/B2 nullable (K2 = 0).  Replaces F.linear (lora.py:144) and the two torch.matmul of

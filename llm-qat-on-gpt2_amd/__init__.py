@@ -8,8 +8,8 @@ from . import _lib
 from .fake_quantize import (LearnableFakeQuantize, LogQuantizationFunction, MinMaxQuantizationFunction,
                             apply_log_quantization, apply_minmax_quantization, fake_quantize)
 from .sp_linear import LoRALayer, SPLinearWithLoRA
-from .calibration import allreduce_calibration_stats, calibrate_layer, calibrate_model
+from .calibration import SpqComm, allreduce_calibration_stats, calibrate_layer, calibrate_model
 
 __all__ = ["SPLinearWithLoRA", "LoRALayer", "LearnableFakeQuantize", "MinMaxQuantizationFunction",
            "LogQuantizationFunction", "apply_minmax_quantization", "apply_log_quantization", "fake_quantize",
-           "allreduce_calibration_stats", "calibrate_layer", "calibrate_model"]
+           "allreduce_calibration_stats", "calibrate_layer", "calibrate_model", "SpqComm"]

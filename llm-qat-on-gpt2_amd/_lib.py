@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspq.so")
 
 MINMAX, LOG = 0, 1
+COMM_ID_BYTES = 128
 PATH_AUTO, PATH_F32, PATH_F16X2, PATH_U8X2, PATH_F16X3 = 0, 1, 2, 3, 4
 QTYPE_CODE = {"minmax": MINMAX, "log": LOG}
 
@@ -37,6 +38,10 @@ class FwdArgs(C.Structure):
 
 # name -> (restype, argtypes); must list every symbol include/spq.h declares (tests/test_cabi.py checks).
 SIGNATURES = {
+    "spq_comm_unique_id": (_int, [_p]),
+    "spq_comm_init": (_int, [_int, _int, _p, C.POINTER(C.c_void_p)]),
+    "spq_comm_destroy": (_int, [_p]),
+    "spq_allreduce_minmax": (_int, [_p, _p, _sz, _p]),
     "spq_version": (_int, []),
     "spq_last_error": (C.c_char_p, []),
     "spq_device_arch": (_int, [C.c_char_p, _int]),

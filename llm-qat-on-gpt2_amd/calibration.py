@@ -14,6 +14,7 @@ from typing import Iterable, List, Optional
 import torch
 import torch.distributed as dist
 
+from . import _lib
 from .fake_quantize import LearnableFakeQuantize
 
 
@@ -29,7 +30,47 @@ def _collecting_quantizers(module_or_list) -> List[LearnableFakeQuantize]:
     return out
 
 
-def allreduce_calibration_stats(module_or_quantizers, group: Optional[dist.ProcessGroup] = None) -> int:
+class SpqComm:
+    """RCCL communicator held through the C ABI (spq_comm_init / spq_allreduce_minmax, include/spq.h): the binding a
+    host without torch.distributed would use.  ``bootstrap`` ships rank 0's 128-byte id to the other ranks; the default
+    uses the already initialised torch.distributed group (any backend) as that side channel."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        import ctypes
+        lib = _lib.load()
+        buf = ctypes.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.spq_comm_init(rank, world, ctypes.cast(buf, ctypes.c_void_p), ctypes.byref(handle)), 'spq_comm_init')
+        self._h, self.rank, self.world = handle, rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+        buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(_lib.load().spq_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), 'spq_comm_unique_id')
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, group: Optional[dist.ProcessGroup] = None) -> "SpqComm":
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, box[0])
+
+    def allreduce_max_(self, flat: torch.Tensor) -> torch.Tensor:
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        _lib.check(_lib.load().spq_allreduce_minmax(self._h, flat.data_ptr(), flat.numel(), _lib.stream_ptr(flat.device)),
+                   'spq_allreduce_minmax')
+        return flat
+
+    def destroy(self):
+        if self._h is not None and self._h.value:
+            _lib.check(_lib.load().spq_comm_destroy(self._h), 'spq_comm_destroy')
+        self._h = None
+
+
+def allreduce_calibration_stats(module_or_quantizers, group: Optional[dist.ProcessGroup] = None,
+                                comm: Optional[SpqComm] = None) -> int:
     """Merge the running min/max of every collecting quantizer across ranks with ONE collective.
 
     Returns the number of fp32 elements exchanged (0 when not distributed).  Every rank must hold the same
@@ -40,12 +81,17 @@ def allreduce_calibration_stats(module_or_quantizers, group: Optional[dist.Proce
     MIN/MAX it can only pull the global minimum to what the clamp would have produced anyway.
     """
     qs = _collecting_quantizers(module_or_quantizers)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1 or not qs:
+    if comm is None and (not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1):
+        return 0
+    if not qs:
         return 0
     mins = [q.temp_min.reshape(-1) for q in qs]
     maxs = [q.temp_max.reshape(-1) for q in qs]
     flat = torch.cat([-torch.cat(mins), torch.cat(maxs)])           # max(-min) == -min(min)
-    dist.all_reduce(flat, op=dist.ReduceOp.MAX, group=group)
+    if comm is not None:
+        comm.allreduce_max_(flat)                                   # C ABI -> ncclAllReduce(ncclMax) of RCCL
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.MAX, group=group)    # backend "nccl" is RCCL on ROCm
     half = flat.numel() // 2
     off = 0
     for q in qs:
@@ -94,7 +140,7 @@ def _set_calibration_mode(model, flag: bool):
 
 
 def calibrate_model(model: torch.nn.Module, bits: int, batches: Iterable, forward=None,
-                    group: Optional[dist.ProcessGroup] = None, lora: bool = True) -> int:
+                    group: Optional[dist.ProcessGroup] = None, lora: bool = True, comm: Optional[SpqComm] = None) -> int:
     """Calibrate every quantizer of bit-width ``bits`` under ``model`` (any module tree containing
     SPLinearWithLoRA layers; a single layer works too).  ``batches`` yields this rank's calibration inputs;
     ``forward(model, batch)`` defaults to ``model(batch)``.  Returns the element count of the all-reduce."""
@@ -116,7 +162,7 @@ def calibrate_model(model: torch.nn.Module, bits: int, batches: Iterable, forwar
                 forward(model, batch) if forward is not None else model(batch)
     finally:
         _set_calibration_mode(model, False)
-    exchanged = allreduce_calibration_stats(started, group)
+    exchanged = allreduce_calibration_stats(started, group, comm)
     for q in started:
         q.finish_calibration(debug=False)
     if lora:
@@ -124,6 +170,6 @@ def calibrate_model(model: torch.nn.Module, bits: int, batches: Iterable, forwar
     return exchanged
 
 
-def calibrate_layer(layer, bits: int, batches: Iterable, group=None) -> int:
+def calibrate_layer(layer, bits: int, batches: Iterable, group=None, comm: Optional[SpqComm] = None) -> int:
     """Convenience alias: a lone SPLinearWithLoRA is a model of one layer."""
-    return calibrate_model(layer, bits, batches, group=group)
+    return calibrate_model(layer, bits, batches, group=group, comm=comm)

@@ -909,7 +909,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_kernel(GemmF16Args
 // Same kernel on v_mfma_f32_16x16x32_f16 (16 accumulator tiles of 16x16 per wave instead of 4 of 32x32): equal FLOPs
 // per cycle, but the chip may hold a higher clock on this shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).
 #define SPQ_SYNC() do { if (!(DIAG & 64)) __syncthreads(); } while (0)
-template <int DIAG>
+// AL = activation limbs: 1 integer levels (SPQ_PATH_F16X2); 2 two limbs of FQ(x) * 2^G (SPQ_PATH_F16X3), the base segment
+// then alternates [hi limb x (Whi, Wlo)] and [lo limb x Whi] stages.  Compile-time, so that the F16X2 code is untouched.
+template <int DIAG, int AL>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -919,8 +921,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
 
   const int nwg = g.tiles_m * g.tiles_n;
   const int nl = (g.Rp / GK) * 2;           // LoRA stages per tile
-  const int al = g.a_limbs;                 // 1: integer levels; 2: two limbs of FQ(x) * 2^G
-  const int T = nl + al * (g.Kp / GK);      // stages per tile
+  const int T = nl + AL * (g.Kp / GK);      // stages per tile
   const int gstride = (int)gridDim.x;
 
   // XCD-aware tile order (speed only): positions of one XCD (p % 8, observed round-robin placement) map to a
@@ -937,8 +938,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
     bn = (in_band / band_rows) * GN;
   };
 
-  const float lora_to_base = (al == 2) ? g.xscale[0] : 1.f;   // LoRA partial sums carry 2^e[n]; base sums 2^(e[n]+G)
-  const float out_scale = (al == 2) ? g.xscale[1] : 1.f;
+  const float lora_to_base = (AL == 2) ? g.xscale[0] : 1.f;   // LoRA partial sums carry 2^e[n]; base sums 2^(e[n]+G)
+  const float out_scale = (AL == 2) ? g.xscale[1] : 1.f;
   int p = blockIdx.x;
   if (p >= nwg) return;
   int bm, bn;
@@ -960,7 +961,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
     if (t < nl) {
       const int which = t & 1;
       A = which ? g.tlo : g.thi; lda = g.Rp; Bh = g.Bhi; Bl = g.Blo; ldb = g.Rp; k0 = (t >> 1) * GK; two = !which;
-    } else if (al == 1) {
+    } else if (AL == 1) {
       A = g.qx; lda = g.Kp; Bh = g.Whi; Bl = g.Wlo; ldb = g.Kp; k0 = (t - nl) * GK; two = true;
     } else {
       const int tb = t - nl, which = tb & 1;
@@ -1043,7 +1044,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
       ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
       if (n < g.N) {
         ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);
-        ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale;   // exact
+        if (AL == 2) { ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale; }   // exact
         if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
       }
     }
@@ -1059,15 +1060,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                      // C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + e
-          const float ri = g.rowinv[bm + wm * 64 + tm * 16 + 4 * q4 + e] * lora_to_base;
+          float ri = g.rowinv[bm + wm * 64 + tm * 16 + 4 * q4 + e];
+          if (AL == 2) ri *= lora_to_base;
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn) acc[tm][tn][e] *= ri;
         }
     }
-    for (int t = nl; t < T; ++t) {
-      const bool last = (t + 1 == T);
-      const bool two = (al == 1) || !((t - nl) & 1);
-      stage((base + t) & 1, two, !last || more, last ? 0 : t + 1, last ? nbm : bm, last ? nbn : bn);
+    if (AL == 1) {
+      for (int t = nl; t < T; ++t) {
+        const bool last = (t + 1 == T);
+        stage((base + t) & 1, true, !last || more, last ? 0 : t + 1, last ? nbm : bm, last ? nbn : bn);
+      }
+    } else {
+      for (int t = nl; t < T; t += 2) {
+        stage((base + t) & 1, true, true, t + 1, bm, bn);
+        const bool last = (t + 2 == T);
+        stage((base + t + 1) & 1, false, !last || more, last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
+      }
     }
 
     // ---- epilogue: y = acc * 2^-e[n] + bias[n].  Each wave transposes 16 rows x 32 cols at a time through its
@@ -1559,10 +1568,14 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   if (mfma16 < 0) {
     const char* e = getenv("SPQ_MFMA16");
     mfma16 = (e && e[0] == '0') ? 0 : 1;
-    if (mfma16) (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    if (mfma16) {
+      (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    }
   }
   if (x3 && !mfma16) { set_error("spq_linear_lora_fwd: SPQ_PATH_F16X3 needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
-  if (mfma16) gemm_f16x2_s16_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS, st>>>(g);
+  if (mfma16 && x3) gemm_f16x2_s16_kernel<0, 2><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS, st>>>(g);
+  else if (mfma16) gemm_f16x2_s16_kernel<0, 1><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS, st>>>(g);
   else gemm_f16x2_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS, st>>>(g);
   if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
   return check_launch("spq_linear_lora_fwd(gemm_f16x2)");

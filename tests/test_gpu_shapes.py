@@ -278,3 +278,23 @@ def test_block_of_four_linears_with_model_level_calibration(pkg):
     bad = int((row_err > 1.0).sum())
     assert bad <= 0.02 * row_err.numel(), f"{bad} of {row_err.numel()} tokens differ"
     assert float((y - y_ref).norm() / y_ref.norm()) < 5e-3
+
+
+def test_capi_rccl_allreduce_single_rank(pkg):
+    """spq_comm_init / spq_allreduce_minmax (include/spq.h) through RCCL on this GPU: a 1-rank communicator (the box has
+    one card; the 2-rank semantics are covered on CPU by tests/test_dist_gloo.py) leaves the statistics unchanged and
+    calibration through it equals calibration without it."""
+    comm = pkg.SpqComm(0, 1, pkg.SpqComm.unique_id())
+    try:
+        flat = torch.randn(4099, device=DEV)
+        ref = flat.clone()
+        comm.allreduce_max_(flat)
+        torch.cuda.synchronize()
+        assert torch.equal(flat, ref)
+        layer, ol, x0, x1 = make_pair(pkg, 256, 128, 64, 8, 4, "minmax", True, seed=3)
+        s0 = layer.quantizers_input["4bit"].scale.clone()
+        n = pkg.calibrate_layer(layer, 4, [x0.to(DEV), x1.to(DEV)], comm=comm)
+        assert n == 2 * 128
+        assert torch.equal(layer.quantizers_input["4bit"].scale, s0)
+    finally:
+        comm.destroy()

@@ -74,15 +74,15 @@ int main(int argc, char** argv) {
   printf("2x MFMA per stage: mfma-only %.1f | loads+mfma %.1f us\n", run<32 + 13>(g, 30), run<32 + 12>(g, 30));
   printf("no barriers at all: mfma-only %.1f | loads-only %.1f | loads+mfma %.1f us\n", run<64 + 13>(g, 30), run<64 + 2 + 4>(g, 30), run<64 + 12>(g, 30));
   {
-    hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 2; ++rep) {
       float ms[2];
       for (int v = 0; v < 2; ++v) {
-        for (int i = 0; i < 5; ++i) { if (v == 0) gemm_f16x2_s16_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g); else gemm_f16x2_s16_kernel<5><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g); }
+        for (int i = 0; i < 5; ++i) { if (v == 0) gemm_f16x2_s16_kernel<0, 1><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g); else gemm_f16x2_s16_kernel<5, 1><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g); }
         hipEventRecord(a);
-        for (int i = 0; i < 50; ++i) { if (v == 0) gemm_f16x2_s16_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g); else gemm_f16x2_s16_kernel<5><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g); }
+        for (int i = 0; i < 50; ++i) { if (v == 0) gemm_f16x2_s16_kernel<0, 1><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g); else gemm_f16x2_s16_kernel<5, 1><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS>>>(g); }
         hipEventRecord(b); hipEventSynchronize(b);
         hipEventElapsedTime(&ms[v], a, b);
       }
