@@ -44,8 +44,9 @@ enum spq_path {
   SPQ_PATH_F32 = 1,   /* fp32-input MFMA on dequantised fp32 operands: always valid */
   SPQ_PATH_F16X2 = 2, /* exact integer levels (fp16) x 2-limb fp16 weights on f16 MFMA: minmax, symmetric, bits<=12 */
   SPQ_PATH_U8X2 = 3,  /* same arithmetic, levels stored as bytes (bits<=8), 3-slot LDS ring; same prepared operands as F16X2 */
-  SPQ_PATH_F16X3 = 4  /* any input quantizer (log, asymmetric, >12 bit): FQ(x)*2^G as two fp16 limbs x 2-limb weights, three
-                         f16 MFMA products per algorithmic product; operands prepared with sx = 1 (no scale folding) */
+  SPQ_PATH_F16X3 = 4  /* any input quantizer (log, asymmetric, >12 bit) or none at all (quantize_input = 0: plain fp32
+                         activations, e.g. a gradient): FQ(x)*2^G as two fp16 limbs x 2-limb weights, three f16 MFMA
+                         products per algorithmic product; operands prepared with sx = 1 (no scale folding) */
 };
 
 typedef void* spq_stream_t;
@@ -98,6 +99,14 @@ int spq_fakequant(const float* x, int64_t outer, int64_t chan, int64_t inner, co
 int spq_fakequant_transposed(const float* x, int64_t rows, int64_t cols, const float* scale,
                              const float* zp, int per_channel, int bits, int qtype, int symmetric,
                              float out_scaling, float* out_f32, spq_stream_t stream);
+
+/* scale_out2 = {2^G, 2^-G} (device) with max|x| * 2^G in [2^13, 2^14): the x_limb_scale of SPQ_PATH_F16X3 for a tensor
+ * that has no calibrated range -- the incoming gradient g of the backward contraction g . FQ(W)
+ * (quantization_methods.py:25-28: the straight-through backward passes g unchanged).  One HBM pass over x, no host
+ * synchronisation.  workspace: SPQ_LIMB_SCALE_WORKSPACE_BYTES bytes, 16-B aligned. */
+#define SPQ_LIMB_SCALE_WORKSPACE_BYTES 16384
+int spq_dynamic_limb_scale(const float* x, int64_t n, float* scale_out2, void* workspace, size_t workspace_bytes,
+                           spq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * The path's only exchange step: before finish_calibration every rank merges the running
@@ -159,6 +168,10 @@ typedef struct spq_fwd_args {
    * (dense-contraction) kernel, so a benchmark can time that kernel inside its own timed region */
   void* ev_gemm_begin;
   void* ev_gemm_end;
+  /* optional fp32 [M, r] copy of the LoRA-down product x . FQ(A) (lora.py:51): a training forward keeps it for d/dB, and
+   * the backward takes g . FQ(B)^T out of the activation pass of its own contraction.  With r > 0, b_prep may then be
+   * NULL: LoRA-down only, the contraction skips the LoRA-up stages. */
+  float* t_out;
 } spq_fwd_args;
 
 size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path);

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libspq.so")
 
 MINMAX, LOG = 0, 1
 COMM_ID_BYTES = 128
+LIMB_SCALE_WORKSPACE_BYTES = 16384
 PATH_AUTO, PATH_F32, PATH_F16X2, PATH_U8X2, PATH_F16X3 = 0, 1, 2, 3, 4
 QTYPE_CODE = {"minmax": MINMAX, "log": LOG}
 
@@ -33,7 +34,7 @@ class FwdArgs(C.Structure):
                 ("w_prep", _p), ("w_rowscale", _p), ("bias", _p), ("a_prep", _p), ("b_prep", _p),
                 ("lora_scaling", _f),
                 ("y", _p), ("workspace", _p), ("workspace_bytes", _sz),
-                ("ev_gemm_begin", _p), ("ev_gemm_end", _p)]
+                ("ev_gemm_begin", _p), ("ev_gemm_end", _p), ("t_out", _p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/spq.h declares (tests/test_cabi.py checks).
@@ -42,6 +43,7 @@ SIGNATURES = {
     "spq_comm_init": (_int, [_int, _int, _p, C.POINTER(C.c_void_p)]),
     "spq_comm_destroy": (_int, [_p]),
     "spq_allreduce_minmax": (_int, [_p, _p, _sz, _p]),
+    "spq_dynamic_limb_scale": (_int, [_p, _i64, _p, _p, _sz, _p]),
     "spq_version": (_int, []),
     "spq_last_error": (C.c_char_p, []),
     "spq_device_arch": (_int, [C.c_char_p, _int]),

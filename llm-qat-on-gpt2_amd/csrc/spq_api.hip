@@ -72,7 +72,7 @@ extern "C" int spq_linear_lora_fwd(const spq_fwd_args* a, spq_stream_t stream) {
   SPQ_REQUIRE(a->x && a->w_prep && a->y, "spq_linear_lora_fwd: null operand");
   SPQ_REQUIRE(!a->quantize_input || (a->sx && a->zx), "spq_linear_lora_fwd: input scale missing");
   SPQ_REQUIRE(!a->quantize_input || (a->bits >= 1 && a->bits <= 16), "spq_linear_lora_fwd: bits %d outside [1,16]", a->bits);
-  SPQ_REQUIRE(a->r == 0 || (a->a_prep && a->b_prep), "spq_linear_lora_fwd: LoRA operands missing");
+  SPQ_REQUIRE(a->r == 0 || (a->a_prep && (a->b_prep || a->t_out)), "spq_linear_lora_fwd: LoRA operands missing");
   SPQ_REQUIRE(a->workspace && aligned16(a->workspace), "spq_linear_lora_fwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
   if (a->workspace_bytes < spq_fwd_workspace_bytes(a->M, a->K, a->N, a->r, a->path)) {
@@ -88,7 +88,8 @@ extern "C" int spq_linear_lora_fwd(const spq_fwd_args* a, spq_stream_t stream) {
   // ---- F32 path: [x -> FQ(x)] , [t = x . FQ(A)] , [y = FQ(x) . FQ(W)^T + bias + s * t . FQ(B)]
   char* ws = (char*)a->workspace;
   float* xq = (float*)ws;
-  float* t = (float*)(ws + align_up((size_t)a->M * a->K * sizeof(float), 256));
+  float* t = a->t_out ? a->t_out : (float*)(ws + align_up((size_t)a->M * a->K * sizeof(float), 256));
+  const bool lora_up = a->r > 0 && a->b_prep != nullptr;
   int rc;
   if (a->r > 0) {  // lora.py:51 on the RAW x
     rc = launch_gemm_f32_nt(a->x, a->K, a->a_prep, a->K, a->K, nullptr, 0, nullptr, 0, 0, 1.f, nullptr, t, a->r,
@@ -103,9 +104,9 @@ extern "C" int spq_linear_lora_fwd(const spq_fwd_args* a, spq_stream_t stream) {
     act = xq;
   }
   if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
-  rc = launch_gemm_f32_nt(act, a->K, (const float*)a->w_prep, a->K, a->K, a->r > 0 ? t : nullptr, a->r,
-                          (const float*)a->b_prep, a->r, a->r, a->lora_scaling, a->bias, a->y, a->N, a->M, a->N,
-                          st);
+  rc = launch_gemm_f32_nt(act, a->K, (const float*)a->w_prep, a->K, a->K, lora_up ? t : nullptr, a->r,
+                          (const float*)a->b_prep, a->r, lora_up ? a->r : 0, a->lora_scaling, a->bias, a->y, a->N, a->M,
+                          a->N, st);
   if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
   return rc;
 }

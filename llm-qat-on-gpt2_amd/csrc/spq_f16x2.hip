@@ -218,6 +218,7 @@ struct XPassArgs {
   int limbs, qtype, symmetric;
   _Float16* xl;
   const float* xscale;                      // device {2^G, 2^-G}: power of two that puts the quantizer's range bound at 2^14
+  float* t_out;                             // optional fp32 [M, r]: the LoRA-down product itself
 };
 
 // One WAVE per output row (4 rows per workgroup): the row's FQ(W) values stay in registers between the max pass and
@@ -363,6 +364,16 @@ __device__ __forceinline__ void xpass_finish(const XPassArgs& a, const f32x16 (&
       for (int j = 0; j < 8; ++j) split2(tv[sgi][j] * p, hi.h[j], lo.h[j]);   // * p exact (power of two)
       *reinterpret_cast<uint4*>(a.thi + (int64_t)m * a.Rp + c0) = hi.u;
       *reinterpret_cast<uint4*>(a.tlo + (int64_t)m * a.Rp + c0) = lo.u;
+      if (a.t_out) {
+        float* to = a.t_out + (int64_t)m * a.r + c0;
+        if ((a.r & 3) == 0 && c0 + 8 <= a.r) {
+          *reinterpret_cast<float4*>(to) = make_float4(tv[sgi][0], tv[sgi][1], tv[sgi][2], tv[sgi][3]);
+          *reinterpret_cast<float4*>(to + 4) = make_float4(tv[sgi][4], tv[sgi][5], tv[sgi][6], tv[sgi][7]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (c0 + j < a.r) to[j] = tv[sgi][j];
+        }
+      }
     }
   }
 }
@@ -1478,8 +1489,8 @@ unsigned gemm_grid(int ntiles) {
 int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   const bool x3 = a->path == SPQ_PATH_F16X3;
   if (x3) {
-    if (!(a->quantize_input && a->bits >= 1 && a->bits <= 16 && a->x_limb_scale)) {
-      set_error("spq_linear_lora_fwd: SPQ_PATH_F16X3 needs a calibrated input quantizer (1..16 bits) and x_limb_scale");
+    if (!((!a->quantize_input || (a->bits >= 1 && a->bits <= 16)) && a->x_limb_scale)) {
+      set_error("spq_linear_lora_fwd: SPQ_PATH_F16X3 needs x_limb_scale (and 1..16 bits when quantize_input is set)");
       return SPQ_ERR_UNSUPPORTED;
     }
   } else if (!(a->quantize_input && a->qtype == SPQ_MINMAX && a->symmetric && a->bits >= 2 && a->bits <= 12)) {
@@ -1504,7 +1515,12 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   x.M = (int)a->M; x.K = (int)a->K; x.r = (int)a->r; x.Kp = (int)L.Kp; x.Rp = (int)L.Rp;
   x.x_pc = a->x_per_channel; x.bits = a->bits;
   x.limbs = x3 ? 1 : 0; x.qtype = a->qtype; x.symmetric = a->symmetric;
+  if (x3 && !a->quantize_input) {   // identity quantizer: limbs of x itself; the scale loads read a valid dummy
+    x.bits = 32; x.qtype = SPQ_MINMAX; x.symmetric = 1; x.x_pc = 0; x.sx = a->x_limb_scale; x.zx = a->x_limb_scale;
+  }
   x.xl = (_Float16*)(ws + L.off_xl); x.xscale = a->x_limb_scale;
+  x.t_out = (a->r > 0) ? a->t_out : nullptr;
+  const bool lora_up = a->r > 0 && a->b_prep != nullptr;     // r > 0 without b_prep: LoRA-down only (t_out)
   if (a->path == SPQ_PATH_U8X2 && a->bits > 8) {
     set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 needs an input quantizer of at most 8 bits (got %d)", a->bits);
     return SPQ_ERR_UNSUPPORTED;
@@ -1512,8 +1528,8 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   const bool a8 = a->path == SPQ_PATH_U8X2;   // levels as bytes + 3-slot ring kernel (opt-in)
   x.a8 = a8 ? 1 : 0;
   const unsigned xgrid = (unsigned)((a->M + XR - 1) / XR);
-  const bool panel_ok = (a->K % 64 == 0) && L.Rp <= 64 && aligned16(a->x) && (a->r == 0 || aligned16(a->a_prep)) &&
-                        (!a->x_per_channel || aligned16(a->sx));
+  const bool panel_ok = (a->K % 64 == 0) && L.Rp <= 64 && aligned16(a->x) && (a->r == 0 || aligned16(a->a_prep)) && aligned16(x.sx) &&
+                        aligned16(x.zx);
   if (panel_ok) {
     static bool xattr = false;
     if (!xattr) {
@@ -1533,7 +1549,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     u.Whi = (const _Float16*)(wp + P.off_whi); u.Wlo = (const _Float16*)(wp + P.off_wlo);
     u.Bhi = (const _Float16*)(wp + P.off_bhi); u.Blo = (const _Float16*)(wp + P.off_blo);
     u.rowinv = x.rowinv; u.rowscale = a->w_rowscale; u.bias = a->bias; u.y = a->y;
-    u.M = (int)a->M; u.N = (int)a->N; u.Kp = (int)L.Kp; u.Rp = (int)L.Rp;
+    u.M = (int)a->M; u.N = (int)a->N; u.Kp = (int)L.Kp; u.Rp = lora_up ? (int)L.Rp : 0;
     u.tiles_m = (int)(L.Mp / GM); u.tiles_n = (int)(P.Np / GN);
     static bool uattr = false;
     if (!uattr) {
@@ -1551,7 +1567,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   g.Whi = (const _Float16*)(wp + P.off_whi); g.Wlo = (const _Float16*)(wp + P.off_wlo);
   g.Bhi = (const _Float16*)(wp + P.off_bhi); g.Blo = (const _Float16*)(wp + P.off_blo);
   g.rowinv = x.rowinv; g.rowscale = a->w_rowscale; g.bias = a->bias; g.y = a->y;
-  g.M = (int)a->M; g.N = (int)a->N; g.Kp = (int)L.Kp; g.Rp = (int)L.Rp;
+  g.M = (int)a->M; g.N = (int)a->N; g.Kp = (int)L.Kp; g.Rp = lora_up ? (int)L.Rp : 0;
   g.tiles_m = (int)(L.Mp / GM); g.tiles_n = (int)(P.Np / GN); g.dbg = nullptr;
   g.xl = x.xl; g.xscale = a->x_limb_scale; g.a_limbs = x3 ? 2 : 1;
   static bool attr_set = false;

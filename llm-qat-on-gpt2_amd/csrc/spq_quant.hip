@@ -171,6 +171,29 @@ __global__ __launch_bounds__(1024) void stats_merge_kernel(const float* __restri
   }
 }
 
+// {2^G, 2^-G} with max|x| * 2^G in [2^13, 2^14): the scale of the two-fp16-limb operand of an un-quantised tensor
+// (the incoming gradient of the backward GEMM).  One block over the per-slab maxima of stats_flat_kernel<true>.
+__global__ __launch_bounds__(256) void limb_scale_kernel(const float* __restrict__ pmax, int S, float* __restrict__ out2) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < S; i += 256) m = fmaxf(m, pmax[i]);
+  m = wave_max(m);
+  __shared__ float sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float p = 1.f;
+    if (m > 0.f && m < INFINITY) {
+      int e;
+      (void)frexpf(m * (1.f + 0x1p-10f), &e);          // m = f * 2^e, f in [0.5, 1)
+      e = 14 - e;
+      e = e > 100 ? 100 : (e < -100 ? -100 : e);
+      p = ldexpf(1.f, e);
+    }
+    out2[0] = p; out2[1] = 1.f / p;                      // exact: p is a power of two
+  }
+}
+
 // =================================================================================================
 // finish_calibration: running min/max -> scale, zero_point            quantization.py:110-127
 // =================================================================================================
@@ -393,6 +416,24 @@ extern "C" int spq_minmax_stats(const float* x, int64_t outer, int64_t chan, int
   stats_merge_kernel<<<1, 1024, 0, st>>>(pmin, pmax, S, C, log_domain, eps, log_eps_fill, first_batch, min_io,
                                          max_io);
   return check_launch("spq_minmax_stats(merge)");
+}
+
+extern "C" int spq_dynamic_limb_scale(const float* x, int64_t n, float* scale_out2, void* workspace,
+                                      size_t workspace_bytes, spq_stream_t stream) {
+  SPQ_REQUIRE(x && scale_out2 && workspace && n > 0, "spq_dynamic_limb_scale: null pointer or empty tensor");
+  constexpr int kSlabs = SPQ_LIMB_SCALE_WORKSPACE_BYTES / 8;     // {min, max} partial per slab
+  if (workspace_bytes < SPQ_LIMB_SCALE_WORKSPACE_BYTES || !aligned16(workspace)) {
+    set_error("spq_dynamic_limb_scale: workspace too small or misaligned (%zu bytes)", workspace_bytes);
+    return SPQ_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  int64_t slabs = std::min<int64_t>(kSlabs, std::max<int64_t>(1, n / 4096));
+  const int64_t chunk = ceil_div64(ceil_div64(n, slabs), 4) * 4;
+  slabs = ceil_div64(n, chunk);
+  stats_flat_kernel<true><<<(unsigned)slabs, kStatsBlock, 0, st>>>(x, n, chunk, ws, ws + kSlabs);
+  limb_scale_kernel<<<1, 256, 0, st>>>(ws + kSlabs, (int)slabs, scale_out2);
+  return check_launch("spq_dynamic_limb_scale");
 }
 
 extern "C" int spq_finish_scale(const float* rmin, const float* rmax, int64_t len, int bits, int qtype,

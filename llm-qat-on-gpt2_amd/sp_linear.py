@@ -74,6 +74,69 @@ def _gemm_nt(a, b_nk, bias=None):
     return out
 
 
+class _LimbGemm:
+    """out[M, R] = a[M, C] . b[R, C]^T with fp32-level accuracy on the f16 MFMA kernel of SPQ_PATH_F16X3: ``b`` is split
+    into two fp16 limbs per row (spq_prepare_f16x2 with an identity quantizer), ``a`` into two limbs of a * 2^G with G
+    from max|a| found on the device (spq_dynamic_limb_scale).  Used by the backward pass, whose left operand -- the
+    incoming gradient -- has no calibrated range.  Buffers are kept per (R, C) and reused."""
+
+    def __init__(self):
+        self.key = None
+
+    @staticmethod
+    def supported(R: int, C: int) -> bool:
+        return R % 4 == 0 and R > 0 and C > 0
+
+    def _buffers(self, R, C, device):
+        if self.key != (R, C, device):
+            lib = _lib.load()
+            self.w = torch.empty(lib.spq_prep_f16x2_bytes(R, C, 0), dtype=torch.uint8, device=device)
+            self.rowscale = torch.empty((R + 127) // 128 * 128, dtype=torch.float32, device=device)
+            self.xscale = torch.empty(2, dtype=torch.float32, device=device)
+            self.key = (R, C, device)
+
+    def __call__(self, a: torch.Tensor, b: torch.Tensor, down: torch.Tensor = None):
+        """``down`` [r, C] (optional, r <= 128): also returns a . down^T [M, r], computed inside the activation pass."""
+        M, C = a.shape
+        R = b.shape[0]
+        assert b.shape[1] == C and a.is_contiguous() and b.is_contiguous() and self.supported(R, C)
+        dev = a.device
+        self._buffers(R, C, dev)
+        lib = _lib.load()
+        one = _ones(dev)
+        out = torch.empty(M, R, dtype=torch.float32, device=dev)
+        st = _lib.stream_ptr(dev)
+        r, t, down_p = 0, None, None
+        if down is not None:
+            r = down.shape[0]
+            r_pad = (r + 63) // 64 * 64
+            down_p = down.contiguous()
+            if r_pad != r:                                   # the activation pass copies whole 64-row pieces
+                down_p = torch.zeros(r_pad, C, dtype=torch.float32, device=dev)
+                down_p[:r] = down
+            t = torch.empty(M, r, dtype=torch.float32, device=dev)
+        sws = _lib.LIMB_SCALE_WORKSPACE_BYTES
+        ws = _lib.workspace(dev, lib.spq_fwd_workspace_bytes(M, C, R, r, _lib.PATH_F16X3) + sws + 256)
+        stats_ptr = ws.data_ptr() + (ws.numel() - sws) // 256 * 256
+        with torch.cuda.device(dev):
+            rc = lib.spq_prepare_f16x2(b.data_ptr(), R, C, one.data_ptr(), one.data_ptr(), 0, 32, 0, 1,
+                                       None, 0, None, None, 0, 0, 0, 1, 0.0, None, None, None, 0, 0, 0, 1,
+                                       one.data_ptr(), 0, self.w.data_ptr(), self.w.numel(), self.rowscale.data_ptr(),
+                                       None, st)
+            _lib.check(rc, "spq_prepare_f16x2(backward)")
+            rc = lib.spq_dynamic_limb_scale(a.data_ptr(), M * C, self.xscale.data_ptr(), stats_ptr, sws, st)
+            _lib.check(rc, "spq_dynamic_limb_scale")
+            args = _lib.FwdArgs(
+                M=M, K=C, N=R, r=r, bits=32, qtype=0, symmetric=1, quantize_input=0, x_per_channel=0,
+                path=_lib.PATH_F16X3, x=a.data_ptr(), sx=None, zx=None, x_limb_scale=self.xscale.data_ptr(),
+                w_prep=self.w.data_ptr(), w_rowscale=self.rowscale.data_ptr(), bias=None, a_prep=_lib.ptr(down_p),
+                b_prep=None, lora_scaling=0.0, y=out.data_ptr(), workspace=ws.data_ptr(),
+                workspace_bytes=ws.numel() - sws - 256, ev_gemm_begin=None, ev_gemm_end=None, t_out=_lib.ptr(t))
+            rc = lib.spq_linear_lora_fwd(ctypes.byref(args), st)
+            _lib.check(rc, "spq_linear_lora_fwd(backward)")
+        return out if down is None else (out, t)
+
+
 class _Prepared:
     """Weight-side GEMM operands of one bit-width plus the signature of what they were built from."""
     __slots__ = ("sig", "path", "w", "w_rowscale", "a", "b", "r", "x_limb_scale")
@@ -124,6 +187,9 @@ class SPLinearWithLoRA(nn.Module):
         self.cache_operands = True                # reuse prepared operands in eval mode (see _operands)
         self._prepared = {}
         self._gemm_events = None                  # (hipEvent_t, hipEvent_t) around the dominant kernel, for bench.py
+        self.backward_limbs = True                # d/dx on the f16 MFMA limb kernel (False: fp32 MFMA kernel)
+        self._bwd_gemm = None
+        self._last_t = None                       # LoRA-down product of the last training forward (consumed by autograd)
         self._last_path = None                    # operand path of the most recent fused forward
 
     # ---- precision switching (lora.py:105-125): attribute flips only ---------------------------------------
@@ -184,7 +250,7 @@ class SPLinearWithLoRA(nn.Module):
             return base
         return base + lora(x)
 
-    def _forward_fused(self, x, key, qx, qw, lora):
+    def _forward_fused(self, x, key, qx, qw, lora, keep_t=False):
         _lib.require_gpu(x, "SPLinearWithLoRA input")
         _lib.check_device(x.device)
         W = self.linear.weight
@@ -203,6 +269,7 @@ class SPLinearWithLoRA(nn.Module):
                 f"Quantizer not calibrated. Please run calibration first for {qx.quantizer_type} quantizer.")
         elif qx.quantizer_type not in _lib.QTYPE_CODE:
             raise ValueError(f"Unknown quantizer type: {qx.quantizer_type}. Supported types: 'minmax', 'log'")
+        self._last_t = None
         use_lora = (not self.calibration_mode) and lora.enabled and lora.scaling != 0
         prep = self._operands(key, qx, qw, lora, use_lora, quantize_input)
         self._last_path = prep.path
@@ -224,6 +291,8 @@ class SPLinearWithLoRA(nn.Module):
         if quantize_input and (sx.device != x.device or sx.numel() not in (1, K)):
             raise RuntimeError(f"input scale of shape {tuple(sx.shape)} on {sx.device} does not fit input {tuple(x.shape)}")
         bias = self.linear.bias
+        # training: keep the LoRA-down product x . FQ(A) for d/dB instead of recomputing it in the backward
+        self._last_t = torch.empty(M, r, dtype=torch.float32, device=x.device) if (keep_t and r) else None
         a = _lib.FwdArgs(
             M=M, K=K, N=N, r=r, bits=int(qx.num_bits), qtype=_lib.QTYPE_CODE.get(qx.quantizer_type, 0),
             symmetric=1 if qx.symmetric else 0, quantize_input=quantize_input,
@@ -234,7 +303,7 @@ class SPLinearWithLoRA(nn.Module):
             b_prep=_lib.ptr(prep.b) if r else None, lora_scaling=float(lora.scaling) if r else 0.0,
             y=y.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
             ev_gemm_begin=self._gemm_events[0] if self._gemm_events else None,
-            ev_gemm_end=self._gemm_events[1] if self._gemm_events else None)
+            ev_gemm_end=self._gemm_events[1] if self._gemm_events else None, t_out=_lib.ptr(self._last_t))
         with torch.cuda.device(x.device):
             rc = lib.spq_linear_lora_fwd(ctypes.byref(a), _lib.stream_ptr(x.device))
         _lib.check(rc, "spq_linear_lora_fwd")
@@ -395,16 +464,17 @@ class _SPLinearFunction(torch.autograd.Function):
     def forward(ctx, x, W, bias, A, B, module, key):
         qx, qw, lora = module.quantizers_input[key], module.quantizers_weight[key], module.lora_adapters[key]
         with torch.no_grad():
-            y = module._forward_fused(x, key, qx, qw, lora)
+            y = module._forward_fused(x, key, qx, qw, lora, keep_t=A is not None)
         ctx.module, ctx.key = module, key
         ctx.use_lora = A is not None
-        ctx.save_for_backward(x)
+        t, module._last_t = module._last_t, None
+        ctx.save_for_backward(x, t)
         return y
 
     @staticmethod
     def backward(ctx, g):
         module, key = ctx.module, ctx.key
-        (x,) = ctx.saved_tensors
+        x, t_saved = ctx.saved_tensors
         qx, qw, lora = module.quantizers_input[key], module.quantizers_weight[key], module.lora_adapters[key]
         K, N = module.in_features, module.out_features
         need_x, need_W, need_b, need_A, need_B = ctx.needs_input_grad[:5]
@@ -420,15 +490,37 @@ class _SPLinearFunction(torch.autograd.Function):
             lib = _lib.load()
             stream = _lib.stream_ptr(x2.device)
             s = float(lora.scaling) if ctx.use_lora else 0.0
+            log_x = qx.quantizer_type == 'log' and qx.num_bits < 32 and not qx.collecting_stats
+            limbs = need_x and module.backward_limbs and _LimbGemm.supported(K, N)
+            gt = None
             if ctx.use_lora:
                 aq = lora.quantize_A(lora.lora_A.detach())                       # [K, r]
                 bq = lora.quantize_B(lora.lora_B.detach())                       # [r, N]
                 r = aq.shape[1]
-                gt = _gemm_nt(g2, bq.contiguous())                               # g . FQ(B)^T  -> [M, r]
-            if need_x:
+                if not (limbs and r <= 128):                                     # else: out of the limb GEMM's activation pass
+                    gt = _gemm_nt(g2, bq.contiguous())                           # g . FQ(B)^T  -> [M, r]
+            if limbs:
+                # g . W_eff on the f16 MFMA kernel: minmax STE is the identity, so both terms share the left operand and
+                # W_eff^T = FQ(W)^T + s * FQ(A) . FQ(B)  [K, N] is formed once (0.3 GFLOP); log STE clamps the base term only
+                wq = qw(module.linear.weight.detach())
+                if ctx.use_lora and not log_x:
+                    w_t = torch.addmm(wq.t(), aq, bq, alpha=s)
+                else:
+                    w_t = wq.t().contiguous()
+                if module._bwd_gemm is None:
+                    module._bwd_gemm = _LimbGemm()
+                if ctx.use_lora and gt is None:
+                    gx, gt = module._bwd_gemm(g2, w_t, down=bq)                  # g . FQ(B)^T rides the activation pass
+                else:
+                    gx = module._bwd_gemm(g2, w_t)
+                if log_x:
+                    gx = torch.clamp(gx, -10, 10)
+                    if ctx.use_lora:
+                        gx = gx + s * _gemm_nt(gt, aq.contiguous())
+                gx = gx.view(x.shape)
+            elif need_x:
                 wq_t = qw(module.linear.weight.detach()).t().contiguous()        # FQ(W)^T [K, N], N contiguous
                 gx = torch.empty(M, K, dtype=torch.float32, device=x2.device)
-                log_x = qx.quantizer_type == 'log' and qx.num_bits < 32 and not qx.collecting_stats
                 with torch.cuda.device(x2.device):
                     if ctx.use_lora and not log_x:                               # both terms in one launch
                         rc = lib.spq_gemm_f32_nt(g2.data_ptr(), N, wq_t.data_ptr(), N, N, gt.data_ptr(), r,
@@ -445,7 +537,7 @@ class _SPLinearFunction(torch.autograd.Function):
             if ctx.use_lora and need_A:
                 gA = ste(s * (x2.t() @ gt), lora.quantize_A)
             if ctx.use_lora and need_B:
-                t = _gemm_nt(x2, aq.t().contiguous())                            # x . FQ(A)  -> [M, r]
+                t = t_saved if t_saved is not None else _gemm_nt(x2, aq.t().contiguous())   # x . FQ(A)  -> [M, r]
                 gB = ste(s * (t.t() @ g2), lora.quantize_B)
             if need_W:
                 xq = qx(x2) if (qx.num_bits < 32 and qx.calibrated and not qx.collecting_stats) else x2

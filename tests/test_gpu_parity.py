@@ -294,6 +294,14 @@ def test_backward_against_reference_autograd(pkg, name):
     assert_close_y(lo.lora_A.grad, t["grad_A"], f"{name}.grad_A", 2e-5)
     assert_close_y(lo.lora_B.grad, t["grad_B"], f"{name}.grad_B", 2e-5)
     assert layer.linear.weight.grad is None
+    # same gradients from the fp32-MFMA contraction (backward_limbs = False)
+    layer.backward_limbs = False
+    lo.lora_A.grad = None; lo.lora_B.grad = None
+    xg1 = t["xg"].to(DEV).requires_grad_(True)
+    layer(xg1).backward(t["g"].to(DEV))
+    assert_close_y(xg1.grad, t["grad_x"], f"{name}.grad_x(f32)", 2e-5)
+    assert_close_y(lo.lora_A.grad, t["grad_A"], f"{name}.grad_A(f32)", 2e-5)
+    layer.backward_limbs = True
     # trainable base weight + bias: straight-through d/dW = g^T . FQ(x), d/db = sum g
     layer.linear.weight.requires_grad_(True); layer.linear.bias.requires_grad_(True)
     xg2 = t["xg"].to(DEV).requires_grad_(True)
