@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SPQ_VERSION 100 /* 0.1.0 */
+#define SPQ_VERSION 101 /* 0.1.1 */
 
 enum spq_status {
   SPQ_OK = 0,
@@ -36,7 +36,12 @@ enum spq_status {
   SPQ_ERR_WORKSPACE = -5    /* workspace too small or misaligned */
 };
 
-enum spq_qtype { SPQ_MINMAX = 0, SPQ_LOG = 1 };
+enum spq_qtype {
+  SPQ_MINMAX = 0,
+  SPQ_LOG = 1,        /* part1_switchable_precision/quantization_methods.py:33-79 */
+  SPQ_LOG_DIRECT = 2  /* part2_cyclic_precision_training/quantization_methods.py:23-47: same levels, the normalised level is
+                         dequantised without part1's * (2^b-1) / (2^b-1) round trip */
+};
 
 /* GEMM operand paths of spq_linear_lora_fwd (see DESIGN.md "Kernels") */
 enum spq_path {
@@ -109,6 +114,16 @@ int spq_dynamic_limb_scale(const float* x, int64_t n, float* scale_out2, void* w
                            spq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Token contraction of the backward pass, fp32-input MFMA:  out[i, j] = alpha * sum_m P[m, i] * Q[m, j]
+ * (out [I, J] contiguous).  d/dA = s * x^T . (g . FQ(B)^T) and d/dB = s * (x . FQ(A))^T . g of LoRALayer.forward
+ * (lora.py:51-52 under autograd): one side is rank-thin, M is long, so the sum is split over M and reduced in a
+ * fixed order (deterministic).  workspace: spq_gemm_f32_tn_workspace_bytes() bytes, 16-B aligned.
+ * ------------------------------------------------------------------------------------------------- */
+size_t spq_gemm_f32_tn_workspace_bytes(int64_t M, int64_t I, int64_t J);
+int spq_gemm_f32_tn(const float* P, int64_t ldp, const float* Q, int64_t ldq, int64_t M, int64_t I, int64_t J,
+                    float alpha, float* out, void* workspace, size_t workspace_bytes, spq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * The path's only exchange step: before finish_calibration every rank merges the running
  * statistics of its input quantizers (quantization.py:202-207 across ranks) with ONE in-place
  * all-reduce(MAX) over the flat fp32 buffer [-min_0 .. | max_0 ..] -- ncclAllReduce(ncclFloat, ncclMax) of
@@ -172,6 +187,9 @@ typedef struct spq_fwd_args {
    * the backward takes g . FQ(B)^T out of the activation pass of its own contraction.  With r > 0, b_prep may then be
    * NULL: LoRA-down only, the contraction skips the LoRA-up stages. */
   float* t_out;
+  /* 0: the LoRA branch consumes the raw x (part1 SPLinearWithLoRA, lora.py:149); 1: it consumes FQ(x) (part2 CPTLinear,
+   * cpt_model.py:112) */
+  int lora_on_fq_input;
 } spq_fwd_args;
 
 size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path);

@@ -15,7 +15,9 @@ MINMAX, LOG = 0, 1
 COMM_ID_BYTES = 128
 LIMB_SCALE_WORKSPACE_BYTES = 16384
 PATH_AUTO, PATH_F32, PATH_F16X2, PATH_U8X2, PATH_F16X3 = 0, 1, 2, 3, 4
-QTYPE_CODE = {"minmax": MINMAX, "log": LOG}
+LOG_DIRECT = 2
+QTYPE_CODE = {"minmax": MINMAX, "log": LOG}            # part1 quantizers
+QTYPE_CODE_CPT = {"minmax": MINMAX, "log": LOG_DIRECT}  # part2 quantizers (log without the level round trip)
 
 _lib = None
 _p = C.c_void_p
@@ -34,7 +36,7 @@ class FwdArgs(C.Structure):
                 ("w_prep", _p), ("w_rowscale", _p), ("bias", _p), ("a_prep", _p), ("b_prep", _p),
                 ("lora_scaling", _f),
                 ("y", _p), ("workspace", _p), ("workspace_bytes", _sz),
-                ("ev_gemm_begin", _p), ("ev_gemm_end", _p), ("t_out", _p)]
+                ("ev_gemm_begin", _p), ("ev_gemm_end", _p), ("t_out", _p), ("lora_on_fq_input", _int)]
 
 
 # name -> (restype, argtypes); must list every symbol include/spq.h declares (tests/test_cabi.py checks).
@@ -44,6 +46,8 @@ SIGNATURES = {
     "spq_comm_destroy": (_int, [_p]),
     "spq_allreduce_minmax": (_int, [_p, _p, _sz, _p]),
     "spq_dynamic_limb_scale": (_int, [_p, _i64, _p, _p, _sz, _p]),
+    "spq_gemm_f32_tn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "spq_gemm_f32_tn": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _f, _p, _p, _sz, _p]),
     "spq_version": (_int, []),
     "spq_last_error": (C.c_char_p, []),
     "spq_device_arch": (_int, [C.c_char_p, _int]),

@@ -71,7 +71,7 @@ extern "C" int spq_linear_lora_fwd(const spq_fwd_args* a, spq_stream_t stream) {
               (long long)a->M, (long long)a->K, (long long)a->N, (long long)a->r);
   SPQ_REQUIRE(a->x && a->w_prep && a->y, "spq_linear_lora_fwd: null operand");
   SPQ_REQUIRE(!a->quantize_input || (a->sx && a->zx), "spq_linear_lora_fwd: input scale missing");
-  SPQ_REQUIRE(!a->quantize_input || (a->bits >= 1 && a->bits <= 16), "spq_linear_lora_fwd: bits %d outside [1,16]", a->bits);
+  SPQ_REQUIRE(!a->quantize_input || (a->bits >= 1 && a->bits <= 24), "spq_linear_lora_fwd: bits %d outside [1,24]", a->bits);
   SPQ_REQUIRE(a->r == 0 || (a->a_prep && (a->b_prep || a->t_out)), "spq_linear_lora_fwd: LoRA operands missing");
   SPQ_REQUIRE(a->workspace && aligned16(a->workspace), "spq_linear_lora_fwd: workspace missing or misaligned");
   hipStream_t st = (hipStream_t)stream;
@@ -91,17 +91,17 @@ extern "C" int spq_linear_lora_fwd(const spq_fwd_args* a, spq_stream_t stream) {
   float* t = a->t_out ? a->t_out : (float*)(ws + align_up((size_t)a->M * a->K * sizeof(float), 256));
   const bool lora_up = a->r > 0 && a->b_prep != nullptr;
   int rc;
-  if (a->r > 0) {  // lora.py:51 on the RAW x
-    rc = launch_gemm_f32_nt(a->x, a->K, a->a_prep, a->K, a->K, nullptr, 0, nullptr, 0, 0, 1.f, nullptr, t, a->r,
-                            a->M, a->r, st);
-    if (rc) return rc;
-  }
   const float* act = a->x;
   if (a->quantize_input) {  // lora.py:141
     rc = spq_fakequant(a->x, a->M, a->K, 1, a->sx, a->zx, a->x_per_channel, a->bits, a->qtype, a->symmetric, xq,
                        nullptr, 0, stream);
     if (rc) return rc;
     act = xq;
+  }
+  if (a->r > 0) {  // lora.py:51 on the RAW x; cpt_model.py:112 on FQ(x)
+    rc = launch_gemm_f32_nt(a->lora_on_fq_input ? act : a->x, a->K, a->a_prep, a->K, a->K, nullptr, 0, nullptr, 0, 0, 1.f,
+                            nullptr, t, a->r, a->M, a->r, st);
+    if (rc) return rc;
   }
   if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
   rc = launch_gemm_f32_nt(act, a->K, (const float*)a->w_prep, a->K, a->K, lora_up ? t : nullptr, a->r,

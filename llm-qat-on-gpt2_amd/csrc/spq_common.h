@@ -53,7 +53,9 @@ struct LogParams {
   float denom;  // sym: 2*n ; asym: n
 };
 
-__host__ __device__ inline LogParams make_log_params(int bits, bool sym) {
+// direct: part2's log quantizer (part2_cyclic_precision_training/quantization_methods.py:36-40) dequantises
+// q/(2n) + 0.5 as is; part1's (quantization_methods.py:57,:64) sends it through * (2^b-1) / (2^b-1) first.
+__host__ __device__ inline LogParams make_log_params(int bits, bool sym, bool direct = false) {
   LogParams p;
   if (sym) {
     float n = (float)((1 << (bits - 1)) - 1);
@@ -64,7 +66,7 @@ __host__ __device__ inline LogParams make_log_params(int bits, bool sym) {
     float n = (float)((1u << bits) - 1u);
     p.n2 = n; p.qlo = 0.f; p.qhi = n; p.denom = n;
   }
-  p.full = (float)((1u << bits) - 1u);
+  p.full = direct ? 0.f : (float)((1u << bits) - 1u);
   return p;
 }
 
@@ -86,7 +88,10 @@ template <bool SYM>
 __device__ __forceinline__ float log_dequant(float x, float q, float log_min, float log_range,
                                              const LogParams& p) {
   float qn;
-  if (SYM) qn = ((q / p.denom + 0.5f) * p.full) / p.full;          // :57 then :64
+  if (SYM) {
+    qn = q / p.denom + 0.5f;                                       // :57
+    if (p.full > 0.f) qn = (qn * p.full) / p.full;                 // :64 (part1 only)
+  }
   else     qn = q / p.denom;                                       // :66
   float x_hat = qn * log_range + log_min;                          // :68 (unclamped range)
   float mag = exp2_rn(x_hat);                                      // :70

@@ -90,14 +90,14 @@ struct PrepArgs {
 };
 
 template <int QT, bool SYM>
-__device__ __forceinline__ float fq_value(float v, float s, float z, int bits) {
+__device__ __forceinline__ float fq_value(float v, float s, float z, int bits, bool log_direct = false) {
   if (QT == SPQ_MINMAX) {
     float qlo, qhi;
     if (SYM) { qhi = (float)((1 << (bits - 1)) - 1); qlo = -qhi; }
     else { qlo = 0.f; qhi = (float)((1u << bits) - 1u); }
     return minmax_dequant<SYM>(minmax_level<SYM>(v, s, z, qlo, qhi), s, z);
   } else {
-    const LogParams lp = make_log_params(bits, SYM);
+    const LogParams lp = make_log_params(bits, SYM, log_direct);
     return log_dequant<SYM>(v, log_level<SYM>(v, z, s, lp), z, s, lp);
   }
 }
@@ -105,7 +105,8 @@ __device__ __forceinline__ float fq_value(float v, float s, float z, int bits) {
 __device__ __forceinline__ float fq_dispatch(float v, float s, float z, int bits, int qtype, int sym) {
   if (bits >= 32) return v;
   if (qtype == SPQ_MINMAX) return sym ? fq_value<SPQ_MINMAX, true>(v, s, z, bits) : fq_value<SPQ_MINMAX, false>(v, s, z, bits);
-  return sym ? fq_value<SPQ_LOG, true>(v, s, z, bits) : fq_value<SPQ_LOG, false>(v, s, z, bits);
+  const bool direct = qtype == SPQ_LOG_DIRECT;
+  return sym ? fq_value<SPQ_LOG, true>(v, s, z, bits, direct) : fq_value<SPQ_LOG, false>(v, s, z, bits, direct);
 }
 
 // v = hi + lo up to 2^-22 |v|: hi = RN_f16(v), lo = RN_f16(v - hi); the residual is exact in fp32 (hi carries 11 of
@@ -219,6 +220,7 @@ struct XPassArgs {
   _Float16* xl;
   const float* xscale;                      // device {2^G, 2^-G}: power of two that puts the quantizer's range bound at 2^14
   float* t_out;                             // optional fp32 [M, r]: the LoRA-down product itself
+  int lora_fq;                              // 1: the LoRA-down product consumes FQ(x) (part2 CPTLinear), 0: raw x (part1)
 };
 
 // One WAVE per output row (4 rows per workgroup): the row's FQ(W) values stay in registers between the max pass and
@@ -406,6 +408,12 @@ __device__ __forceinline__ void store_act4(const XPassArgs& a, int64_t idx, floa
   }
 }
 
+// FQ of four consecutive activations (the LoRA-down operand of part2's CPTLinear, cpt_model.py:112)
+__device__ __forceinline__ float4 fq_act4(const XPassArgs& a, float4 v, float4 sc, float4 zp) {
+  return make_float4(fq_dispatch(v.x, sc.x, zp.x, a.bits, a.qtype, a.symmetric), fq_dispatch(v.y, sc.y, zp.y, a.bits, a.qtype, a.symmetric),
+                     fq_dispatch(v.z, sc.z, zp.z, a.bits, a.qtype, a.symmetric), fq_dispatch(v.w, sc.w, zp.w, a.bits, a.qtype, a.symmetric));
+}
+
 // four consecutive integer levels -> level matrix at element index idx (fp16, or bytes q + 128 when a8)
 __device__ __forceinline__ void store_levels4(_Float16* qx, int64_t idx, float q0, float q1, float q2, float q3, int a8) {
   if (a8) {
@@ -490,20 +498,27 @@ __global__ __launch_bounds__(256) void xpass_kernel(XPassArgs a) {
       const int idx = tid + 256 * i, row = idx >> 4, c = (idx & 15) << 2;
       const int m = m0 + row, k = k0 + c;
       const float4 v = rx[i];
-      *reinterpret_cast<float4*>(xs + row * XLD + c) = v;
       float s0, s1, s2, s3;
       if (a.x_pc) {
         s0 = (k + 0 < a.K) ? a.sx[k + 0] : 1.f; s1 = (k + 1 < a.K) ? a.sx[k + 1] : 1.f;
         s2 = (k + 2 < a.K) ? a.sx[k + 2] : 1.f; s3 = (k + 3 < a.K) ? a.sx[k + 3] : 1.f;
       } else { s0 = s1 = s2 = s3 = a.sx[0]; }
-      if (m < a.M) {                                                                 // k < Kp always; pad k -> level 0
-        float4 zp4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.limbs) {
-          if (a.x_pc) {
-            zp4.x = (k + 0 < a.K) ? a.zx[k + 0] : 0.f; zp4.y = (k + 1 < a.K) ? a.zx[k + 1] : 0.f;
-            zp4.z = (k + 2 < a.K) ? a.zx[k + 2] : 0.f; zp4.w = (k + 3 < a.K) ? a.zx[k + 3] : 0.f;
-          } else { const float z1 = a.zx[0]; zp4 = make_float4(z1, z1, z1, z1); }
+      float4 zp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.limbs || a.lora_fq) {
+        if (a.x_pc) {
+          zp4.x = (k + 0 < a.K) ? a.zx[k + 0] : 0.f; zp4.y = (k + 1 < a.K) ? a.zx[k + 1] : 0.f;
+          zp4.z = (k + 2 < a.K) ? a.zx[k + 2] : 0.f; zp4.w = (k + 3 < a.K) ? a.zx[k + 3] : 0.f;
+        } else { const float z1 = a.zx[0]; zp4 = make_float4(z1, z1, z1, z1); }
+      }
+      {
+        float4 lv = v;                                                               // LoRA-down operand: raw x, or FQ(x)
+        if (a.lora_fq) {
+          lv = fq_act4(a, v, make_float4(s0, s1, s2, s3), zp4);
+          if (k + 0 >= a.K) lv.x = 0.f; if (k + 1 >= a.K) lv.y = 0.f; if (k + 2 >= a.K) lv.z = 0.f; if (k + 3 >= a.K) lv.w = 0.f;
         }
+        *reinterpret_cast<float4*>(xs + row * XLD + c) = lv;
+      }
+      if (m < a.M) {                                                                 // k < Kp always; pad k -> level 0
         float4 vv = v;
         if (a.limbs) {                                                               // pad columns must come out as zero limbs
           if (k + 0 >= a.K) vv.x = 0.f; if (k + 1 >= a.K) vv.y = 0.f; if (k + 2 >= a.K) vv.z = 0.f; if (k + 3 >= a.K) vv.w = 0.f;
@@ -619,7 +634,7 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
     for (int c = 0; c < nch; ++c) glds16(x_src + p0 + c * 64, xs + c * (XR * 256) + w * 1024);
     for (int k = tid; k < nch * 64; k += 512) {
       sxs[k] = a.x_pc ? a.sx[p0 + k] : a.sx[0];
-      sxs[XP_CHUNKS * 64 + k] = a.limbs ? (a.x_pc ? a.zx[p0 + k] : a.zx[0]) : 0.f;
+      sxs[XP_CHUNKS * 64 + k] = (a.limbs || a.lora_fq) ? (a.x_pc ? a.zx[p0 + k] : a.zx[0]) : 0.f;
     }
     if (with_lora && p0 == 0) SPQ_STORE_A(0);
     __syncthreads();                                       // vmcnt(0): the panel landed; FQ(A)^T chunk gc is in LDS
@@ -637,7 +652,10 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
       // ---- t += x . FQ(A): wave w owns k in [8w, 8w+8) of the chunk, lane half h the 4 contiguous k 8w+4h..+3
       if (with_lora) {
         const int pa = 2 * w + h;                          // 16-B source chunk of this lane
-        const float4 av = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + l31 * 256 + ((pa ^ (l31 & 15)) << 4));
+        float4 av = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + l31 * 256 + ((pa ^ (l31 & 15)) << 4));
+        if (a.lora_fq)                                     // every element is read by exactly one lane: FQ it in place
+          av = fq_act4(a, av, *reinterpret_cast<const float4*>(sxs + c * 64 + 4 * pa),
+                       *reinterpret_cast<const float4*>(sxs + XP_CHUNKS * 64 + c * 64 + 4 * pa));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int rb = t * 32 + l31;
@@ -1489,8 +1507,8 @@ unsigned gemm_grid(int ntiles) {
 int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   const bool x3 = a->path == SPQ_PATH_F16X3;
   if (x3) {
-    if (!((!a->quantize_input || (a->bits >= 1 && a->bits <= 16)) && a->x_limb_scale)) {
-      set_error("spq_linear_lora_fwd: SPQ_PATH_F16X3 needs x_limb_scale (and 1..16 bits when quantize_input is set)");
+    if (!((!a->quantize_input || (a->bits >= 1 && a->bits <= 24)) && a->x_limb_scale)) {
+      set_error("spq_linear_lora_fwd: SPQ_PATH_F16X3 needs x_limb_scale (and 1..24 bits when quantize_input is set)");
       return SPQ_ERR_UNSUPPORTED;
     }
   } else if (!(a->quantize_input && a->qtype == SPQ_MINMAX && a->symmetric && a->bits >= 2 && a->bits <= 12)) {
@@ -1520,6 +1538,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   }
   x.xl = (_Float16*)(ws + L.off_xl); x.xscale = a->x_limb_scale;
   x.t_out = (a->r > 0) ? a->t_out : nullptr;
+  x.lora_fq = (a->lora_on_fq_input && a->quantize_input) ? 1 : 0;
   const bool lora_up = a->r > 0 && a->b_prep != nullptr;     // r > 0 without b_prep: LoRA-down only (t_out)
   if (a->path == SPQ_PATH_U8X2 && a->bits > 8) {
     set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 needs an input quantizer of at most 8 bits (got %d)", a->bits);

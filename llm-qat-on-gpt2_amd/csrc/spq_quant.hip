@@ -203,7 +203,7 @@ __global__ void finish_scale_kernel(const float* __restrict__ rmin, const float*
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= len) return;
   float lo = rmin[i], hi = rmax[i];
-  if (qtype == SPQ_LOG) {                       // :111-117
+  if (qtype != SPQ_MINMAX) {                       // :111-117
     scale[i] = hi - lo;
     zp[i] = lo;
   } else if (symmetric) {                       // :119-123
@@ -226,6 +226,7 @@ struct FQArgs {
   float* out; void* levels;
   int64_t total, chan, inner;
   int per_channel; int bits;
+  int log_direct;
 };
 
 template <typename L>
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void fakequant_kernel(FQArgs a) {
   float qlo, qhi;
   if (SYM) { qhi = (float)((1 << (a.bits - 1)) - 1); qlo = -qhi; }
   else { qlo = 0.f; qhi = (float)((1u << a.bits) - 1u); }
-  const LogParams lp = make_log_params(a.bits, SYM);
+  const LogParams lp = make_log_params(a.bits, SYM, a.log_direct != 0);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (MODE == 0) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.total; i += stride) {
@@ -295,13 +296,13 @@ template <int QT, bool SYM>
 __global__ __launch_bounds__(256) void fakequant_transposed_kernel(const float* __restrict__ x, int64_t rows,
                                                                    int64_t cols, const float* __restrict__ scale,
                                                                    const float* __restrict__ zp, int per_channel,
-                                                                   int bits, float out_scaling,
+                                                                   int bits, int log_direct, float out_scaling,
                                                                    float* __restrict__ out) {
   __shared__ float tile[32][33];
   float qlo, qhi;
   if (SYM) { qhi = (float)((1 << (bits - 1)) - 1); qlo = -qhi; }
   else { qlo = 0.f; qhi = (float)((1u << bits) - 1u); }
-  const LogParams lp = make_log_params(bits, SYM);
+  const LogParams lp = make_log_params(bits, SYM, log_direct != 0);
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int64_t c = (int64_t)blockIdx.x * 32 + tx;
   for (int j = ty; j < 32; j += 8) {
@@ -440,8 +441,8 @@ extern "C" int spq_finish_scale(const float* rmin, const float* rmax, int64_t le
                                 int symmetric, float eps, float* scale_out, float* zp_out, spq_stream_t stream) {
   SPQ_REQUIRE(rmin && rmax && scale_out && zp_out, "spq_finish_scale: null pointer");
   SPQ_REQUIRE(len > 0, "spq_finish_scale: len must be positive");
-  SPQ_REQUIRE(bits >= 1 && bits <= 16, "spq_finish_scale: bits %d outside [1,16]", bits);
-  SPQ_REQUIRE(qtype == SPQ_MINMAX || qtype == SPQ_LOG, "spq_finish_scale: unknown quantizer type %d", qtype);
+  SPQ_REQUIRE(bits >= 1 && bits <= 24, "spq_finish_scale: bits %d outside [1,24]", bits);
+  SPQ_REQUIRE(qtype >= SPQ_MINMAX && qtype <= SPQ_LOG_DIRECT, "spq_finish_scale: unknown quantizer type %d", qtype);
   finish_scale_kernel<<<(unsigned)ceil_div64(len, 256), 256, 0, (hipStream_t)stream>>>(
       rmin, rmax, len, bits, qtype, symmetric, eps, scale_out, zp_out);
   return check_launch("spq_finish_scale");
@@ -468,15 +469,16 @@ extern "C" int spq_fakequant(const float* x, int64_t outer, int64_t chan, int64_
   SPQ_REQUIRE(x && scale && zp, "spq_fakequant: null pointer");
   SPQ_REQUIRE(out_f32 || out_levels, "spq_fakequant: no output requested");
   SPQ_REQUIRE(outer > 0 && chan > 0 && inner > 0, "spq_fakequant: empty tensor");
-  SPQ_REQUIRE(bits >= 1 && bits <= 16, "spq_fakequant: bits %d outside [1,16]", bits);
-  SPQ_REQUIRE(qtype == SPQ_MINMAX || qtype == SPQ_LOG, "spq_fakequant: unknown quantizer type %d", qtype);
+  SPQ_REQUIRE(bits >= 1 && bits <= 24, "spq_fakequant: bits %d outside [1,24]", bits);
+  SPQ_REQUIRE(qtype >= SPQ_MINMAX && qtype <= SPQ_LOG_DIRECT, "spq_fakequant: unknown quantizer type %d", qtype);
   const int lb = out_levels ? levels_bytes : 0;
   SPQ_REQUIRE(lb == 0 || lb == 1 || lb == 2 || lb == 4, "spq_fakequant: levels_bytes must be 1, 2 or 4");
   const int maxlevel = symmetric ? (1 << (bits - 1)) - 1 : (1 << bits) - 1;
   SPQ_REQUIRE(lb == 0 || lb == 4 || maxlevel <= (lb == 1 ? 127 : 32767),
               "spq_fakequant: %d-bit %s levels do not fit int%d", bits, symmetric ? "symmetric" : "asymmetric",
               lb * 8);
-  FQArgs a{x, scale, zp, out_f32, out_levels, outer * chan * inner, chan, inner, per_channel, bits};
+  FQArgs a{x, scale, zp, out_f32, out_levels, outer * chan * inner, chan, inner, per_channel, bits,
+           qtype == SPQ_LOG_DIRECT ? 1 : 0};
   int mode = 0;
   const bool al = aligned16(x) && (!out_f32 || aligned16(out_f32)) && (a.total % 4 == 0);
   if (al && per_channel && inner == 1 && chan % 4 == 0 && aligned16(scale) && aligned16(zp)) mode = 1;
@@ -501,16 +503,16 @@ extern "C" int spq_fakequant_transposed(const float* x, int64_t rows, int64_t co
                                         float out_scaling, float* out_f32, spq_stream_t stream) {
   SPQ_REQUIRE(x && scale && zp && out_f32, "spq_fakequant_transposed: null pointer");
   SPQ_REQUIRE(rows > 0 && cols > 0, "spq_fakequant_transposed: empty tensor");
-  SPQ_REQUIRE(bits >= 1 && bits <= 16, "spq_fakequant_transposed: bits %d outside [1,16]", bits);
-  SPQ_REQUIRE(qtype == SPQ_MINMAX || qtype == SPQ_LOG, "spq_fakequant_transposed: unknown quantizer type %d", qtype);
+  SPQ_REQUIRE(bits >= 1 && bits <= 24, "spq_fakequant_transposed: bits %d outside [1,24]", bits);
+  SPQ_REQUIRE(qtype >= SPQ_MINMAX && qtype <= SPQ_LOG_DIRECT, "spq_fakequant_transposed: unknown quantizer type %d", qtype);
   dim3 grid((unsigned)ceil_div64(cols, 32), (unsigned)ceil_div64(rows, 32));
   hipStream_t st = (hipStream_t)stream;
   if (qtype == SPQ_MINMAX) {
-    if (symmetric) fakequant_transposed_kernel<SPQ_MINMAX, true><<<grid, 256, 0, st>>>(x, rows, cols, scale, zp, per_channel, bits, out_scaling, out_f32);
-    else fakequant_transposed_kernel<SPQ_MINMAX, false><<<grid, 256, 0, st>>>(x, rows, cols, scale, zp, per_channel, bits, out_scaling, out_f32);
+    if (symmetric) fakequant_transposed_kernel<SPQ_MINMAX, true><<<grid, 256, 0, st>>>(x, rows, cols, scale, zp, per_channel, bits, qtype == SPQ_LOG_DIRECT ? 1 : 0, out_scaling, out_f32);
+    else fakequant_transposed_kernel<SPQ_MINMAX, false><<<grid, 256, 0, st>>>(x, rows, cols, scale, zp, per_channel, bits, qtype == SPQ_LOG_DIRECT ? 1 : 0, out_scaling, out_f32);
   } else {
-    if (symmetric) fakequant_transposed_kernel<SPQ_LOG, true><<<grid, 256, 0, st>>>(x, rows, cols, scale, zp, per_channel, bits, out_scaling, out_f32);
-    else fakequant_transposed_kernel<SPQ_LOG, false><<<grid, 256, 0, st>>>(x, rows, cols, scale, zp, per_channel, bits, out_scaling, out_f32);
+    if (symmetric) fakequant_transposed_kernel<SPQ_LOG, true><<<grid, 256, 0, st>>>(x, rows, cols, scale, zp, per_channel, bits, qtype == SPQ_LOG_DIRECT ? 1 : 0, out_scaling, out_f32);
+    else fakequant_transposed_kernel<SPQ_LOG, false><<<grid, 256, 0, st>>>(x, rows, cols, scale, zp, per_channel, bits, qtype == SPQ_LOG_DIRECT ? 1 : 0, out_scaling, out_f32);
   }
   return check_launch("spq_fakequant_transposed");
 }

@@ -74,6 +74,22 @@ def _gemm_nt(a, b_nk, bias=None):
     return out
 
 
+def _gemm_tn(p, q, alpha=1.0):
+    """alpha * p[M,I]^T . q[M,J] -> [I, J]: the token contraction of d/dA and d/dB (spq_gemm_f32_tn, deterministic)."""
+    M, I = p.shape
+    J = q.shape[1]
+    assert q.shape[0] == M and p.is_contiguous() and q.is_contiguous()
+    lib = _lib.load()
+    out = torch.empty(I, J, dtype=torch.float32, device=p.device)
+    nbytes = lib.spq_gemm_f32_tn_workspace_bytes(M, I, J)
+    ws = _lib.workspace(p.device, nbytes)
+    with torch.cuda.device(p.device):
+        rc = lib.spq_gemm_f32_tn(p.data_ptr(), I, q.data_ptr(), J, M, I, J, float(alpha), out.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), _lib.stream_ptr(p.device))
+    _lib.check(rc, "spq_gemm_f32_tn")
+    return out
+
+
 class _LimbGemm:
     """out[M, R] = a[M, C] . b[R, C]^T with fp32-level accuracy on the f16 MFMA kernel of SPQ_PATH_F16X3: ``b`` is split
     into two fp16 limbs per row (spq_prepare_f16x2 with an identity quantizer), ``a`` into two limbs of a * 2^G with G
@@ -535,10 +551,10 @@ class _SPLinearFunction(torch.autograd.Function):
                         gx = gx + s * _gemm_nt(gt, aq.contiguous())
                 gx = gx.view(x.shape)
             if ctx.use_lora and need_A:
-                gA = ste(s * (x2.t() @ gt), lora.quantize_A)
+                gA = ste(_gemm_tn(x2, gt, s), lora.quantize_A)
             if ctx.use_lora and need_B:
                 t = t_saved if t_saved is not None else _gemm_nt(x2, aq.t().contiguous())   # x . FQ(A)  -> [M, r]
-                gB = ste(s * (t.t() @ g2), lora.quantize_B)
+                gB = ste(_gemm_tn(t, g2, s), lora.quantize_B)
             if need_W:
                 xq = qx(x2) if (qx.num_bits < 32 and qx.calibrated and not qx.collecting_stats) else x2
                 gW = ste(g2.t() @ xq.reshape(-1, K), qw)

@@ -298,3 +298,17 @@ def test_capi_rccl_allreduce_single_rank(pkg):
         assert torch.equal(layer.quantizers_input["4bit"].scale, s0)
     finally:
         comm.destroy()
+
+
+@pytest.mark.parametrize("M,I,J", [(8192, 768, 64), (8192, 64, 3072), (1000, 100, 72), (37, 5, 3), (4096, 16, 260)])
+def test_token_contraction_tn(pkg, M, I, J):
+    """spq_gemm_f32_tn (d/dA, d/dB of the LoRA factors): alpha * P^T . Q against fp64, ragged shapes, and bit-identical
+    results run to run (fixed-order reduction over the token slices)."""
+    from llm_qat_on_gpt2_amd.sp_linear import _gemm_tn
+    g = torch.Generator().manual_seed(M + I + J)
+    p = torch.randn(M, I, generator=g).to(DEV)
+    q = torch.randn(M, J, generator=g).to(DEV)
+    out = _gemm_tn(p, q, 0.5)
+    ref = (0.5 * (p.double().t() @ q.double())).float()
+    assert_close_y(out, ref.cpu(), f"tn_{M}_{I}_{J}", 1e-5)
+    assert torch.equal(out, _gemm_tn(p, q, 0.5))
