@@ -11,7 +11,8 @@ namespace spq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TN_T = 64;   // block tile 64 x 64, every wave computes the whole tile over its own tokens
+constexpr int TN_I = 64, TN_J = 128;   // block tile; every wave computes the whole tile over its own tokens
+constexpr int TN_WAVES = 8;
 
 struct GemmTnArgs {
   const float* P; const float* Q;
@@ -21,80 +22,130 @@ struct GemmTnArgs {
   float alpha;
 };
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
-  __shared__ float red[4][32][TN_T];   // 32 KB
+// Fragment trick: lane (l, h) of a wave loads P[m + h][i0 + 2l .. +1] (8 B) and Q[m + h][j0 + 4l .. +3] (16 B); component c
+// of the load is the MFMA operand of the tile whose rows / columns are {2l + c} resp. {4l + c} -- a fixed permutation of
+// the block tile, undone when the accumulators are written out.  2 x 4 MFMAs per pair of tokens and 24 B per lane.
+__global__ __launch_bounds__(64 * TN_WAVES) void gemm_tn_kernel(GemmTnArgs a) {
+  __shared__ float red[TN_WAVES][8][TN_J];          // 32 KB: 8 tile rows of every wave's partial at a time
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const int i0 = blockIdx.x * TN_T, j0 = blockIdx.y * TN_T, s = blockIdx.z;
+  const int i0 = blockIdx.x * TN_I, j0 = blockIdx.y * TN_J, s = blockIdx.z;
   const int m_begin = s * a.rows_per_slice;
   const int m_end = min(a.M, m_begin + a.rows_per_slice);
-  const bool i_ok0 = i0 + l31 < a.I, i_ok1 = i0 + 32 + l31 < a.I;
-  const bool j_ok0 = j0 + l31 < a.J, j_ok1 = j0 + 32 + l31 < a.J;
-  const float* p = a.P + i0 + l31;
-  const float* q = a.Q + j0 + l31;
-  f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-  // tokens of this wave: m_begin + 8 u + 2 w + h, u = 0, 1, ...   (the 4 waves of a block read 8 adjacent rows)
+  const bool vec_p = (a.ldp & 1) == 0 && aligned16(a.P) && i0 + TN_I <= a.I;
+  const bool vec_q = (a.ldq & 3) == 0 && aligned16(a.Q) && j0 + TN_J <= a.J;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ci][cj][e] = 0.f;
+
+  // tokens of this wave: m_begin + 2 w + 16 u + h.  Two register sets: the loads of batch b + 1 are issued before the
+  // MFMAs of batch b (2 x 4 x U MFMAs of 64 cycles cover the HBM latency of the next batch).
   constexpr int U = 4;
-  for (int mb = m_begin + 2 * w; mb < m_end; mb += 8 * U) {
-    float a0[U], a1[U], b0[U], b1[U];
+  float2 pv[2][U]; float4 qv[2][U];
+  auto load_batch = [&](int mb, float2 (&pb)[U], float4 (&qb)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int m = mb + 8 * u + h;
-      const bool ok = m < m_end;
-      const float* pr = p + (int64_t)m * a.ldp;
-      const float* qr = q + (int64_t)m * a.ldq;
-      a0[u] = (ok && i_ok0) ? pr[0] : 0.f;
-      a1[u] = (ok && i_ok1) ? pr[32] : 0.f;
-      b0[u] = (ok && j_ok0) ? qr[0] : 0.f;
-      b1[u] = (ok && j_ok1) ? qr[32] : 0.f;
+      const int m = mb + 2 * TN_WAVES * u + h;
+      pb[u] = make_float2(0.f, 0.f); qb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < m_end) {
+        const float* pr = a.P + (int64_t)m * a.ldp + i0 + 2 * l31;
+        const float* qr = a.Q + (int64_t)m * a.ldq + j0 + 4 * l31;
+        if (vec_p) pb[u] = *reinterpret_cast<const float2*>(pr);
+        else {
+          if (i0 + 2 * l31 < a.I) pb[u].x = pr[0];
+          if (i0 + 2 * l31 + 1 < a.I) pb[u].y = pr[1];
+        }
+        if (vec_q) qb[u] = *reinterpret_cast<const float4*>(qr);
+        else {
+          if (j0 + 4 * l31 + 0 < a.J) qb[u].x = qr[0];
+          if (j0 + 4 * l31 + 1 < a.J) qb[u].y = qr[1];
+          if (j0 + 4 * l31 + 2 < a.J) qb[u].z = qr[2];
+          if (j0 + 4 * l31 + 3 < a.J) qb[u].w = qr[3];
+        }
+      }
     }
+  };
+  auto mfma_batch = [&](const float2 (&pb)[U], const float4 (&qb)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc11, 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u].x, qb[u].x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u].x, qb[u].y, acc[0][1], 0, 0, 0);
+      acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u].x, qb[u].z, acc[0][2], 0, 0, 0);
+      acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u].x, qb[u].w, acc[0][3], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u].y, qb[u].x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u].y, qb[u].y, acc[1][1], 0, 0, 0);
+      acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u].y, qb[u].z, acc[1][2], 0, 0, 0);
+      acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(pb[u].y, qb[u].w, acc[1][3], 0, 0, 0);
     }
+  };
+  constexpr int STEP = 2 * TN_WAVES * U;
+  int mb = m_begin + 2 * w;
+  load_batch(mb, pv[0], qv[0]);
+  while (true) {
+    load_batch(mb + STEP, pv[1], qv[1]);          // past m_end: zeros, no loads
+    mfma_batch(pv[0], qv[0]);
+    mb += STEP;
+    if (mb >= m_end) break;
+    load_batch(mb + STEP, pv[0], qv[0]);
+    mfma_batch(pv[1], qv[1]);
+    mb += STEP;
+    if (mb >= m_end) break;
   }
-  // C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).
-  // The four per-wave partials meet in LDS, 32 tile rows at a time (32 KB), and are summed in a fixed order.
+  // C/D map of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).  Accumulator (ci, cj), MFMA
+  // row rr, column cc is output (i0 + 2 rr + ci, j0 + 4 cc + cj).  Round (ci, g): the 8 MFMA rows 8 g' ... that share
+  // e >> 2 == g, i.e. rr = 8 g + 4 h + (e & 3); the TN_WAVES partials meet in LDS and are summed in a fixed order.
   float* dst = a.part + (a.S > 1 ? (int64_t)s * a.I * a.ldo : 0);
   const float scale = a.S > 1 ? 1.f : a.alpha;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (half) __syncthreads();
+  for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-      red[w][row][l31] = half ? acc10[e] : acc00[e];
-      red[w][row][32 + l31] = half ? acc11[e] : acc01[e];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 32 * TN_T; idx += 256) {
-      const int r = idx >> 6, c = idx & 63, i = i0 + 32 * half + r;
-      if (i < a.I && j0 + c < a.J) {
-        const float v = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);     // fixed order
-        dst[(int64_t)i * a.ldo + j0 + c] = v * scale;
+    for (int g = 0; g < 4; ++g) {
+      __syncthreads();
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const int lr = 4 * h + e4;                     // local row 0..7 <-> MFMA row rr = 8 g + lr
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) red[w][lr][4 * l31 + cj] = acc[ci][cj][4 * g + e4];
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 8 * TN_J; idx += 64 * TN_WAVES) {
+        const int lr = idx >> 7, c = idx & (TN_J - 1);
+        const int i = i0 + 2 * (8 * g + lr) + ci, j = j0 + c;
+        if (i < a.I && j < a.J) {
+          float v = red[0][lr][c];
+#pragma unroll
+          for (int q = 1; q < TN_WAVES; ++q) v += red[q][lr][c];          // fixed order
+          dst[(int64_t)i * a.ldo + j] = v * scale;
+        }
       }
     }
-  }
 }
 
-// out = alpha * sum_s part[s]   (fixed order)
+// out = alpha * sum_s part[s]   (fixed order; four independent loads in flight per thread)
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, int S, int64_t n, float alpha,
                                                              float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float v = part[i];
-  for (int s = 1; s < S; ++s) v += part[(int64_t)s * n + i];
+  int s = 1;
+  for (; s + 3 < S; s += 4) {
+    const float v0 = part[(int64_t)s * n + i], v1 = part[(int64_t)(s + 1) * n + i];
+    const float v2 = part[(int64_t)(s + 2) * n + i], v3 = part[(int64_t)(s + 3) * n + i];
+    v = (((v + v0) + v1) + v2) + v3;
+  }
+  for (; s < S; ++s) v += part[(int64_t)s * n + i];
   out[i] = v * alpha;
 }
 
 static int tn_slices(int64_t M, int64_t I, int64_t J) {
-  const int64_t tiles = ((I + TN_T - 1) / TN_T) * ((J + TN_T - 1) / TN_T);
-  int64_t S = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU
-  const int64_t max_s = (M + 63) / 64;                    // at least 64 tokens per slice
+  const int64_t tiles = ((I + TN_I - 1) / TN_I) * ((J + TN_J - 1) / TN_J);
+  int64_t S = 512 / tiles;                                // <= 2 full rounds of one 8-wave workgroup per CU
+  const int64_t max_s = (M + 16 * TN_WAVES - 1) / (16 * TN_WAVES);   // at least 16 tokens per wave
   if (S > max_s) S = max_s;
-  if (S > 256) S = 256;
+  if (S > 128) S = 128;
   return (int)(S < 1 ? 1 : S);
 }
 
@@ -123,10 +174,10 @@ extern "C" int spq_gemm_f32_tn(const float* P, int64_t ldp, const float* Q, int6
   GemmTnArgs a;
   a.P = P; a.Q = Q; a.ldp = ldp; a.ldq = ldq; a.ldo = J;
   a.M = (int)M; a.I = (int)I; a.J = (int)J; a.S = S; a.alpha = alpha;
-  a.rows_per_slice = (int)(((M + S - 1) / S + 7) / 8 * 8);
+  a.rows_per_slice = (int)(((M + S - 1) / S + 15) / 16 * 16);
   a.part = S > 1 ? (float*)workspace : out;
-  dim3 grid((unsigned)((I + TN_T - 1) / TN_T), (unsigned)((J + TN_T - 1) / TN_T), (unsigned)S);
-  gemm_tn_kernel<<<grid, 256, 0, st>>>(a);
+  dim3 grid((unsigned)((I + TN_I - 1) / TN_I), (unsigned)((J + TN_J - 1) / TN_J), (unsigned)S);
+  gemm_tn_kernel<<<grid, 64 * TN_WAVES, 0, st>>>(a);
   int rc = check_launch("spq_gemm_f32_tn");
   if (rc || S == 1) return rc;
   const int64_t n = I * J;

@@ -79,6 +79,8 @@ def _gemm_tn(p, q, alpha=1.0):
     M, I = p.shape
     J = q.shape[1]
     assert q.shape[0] == M and p.is_contiguous() and q.is_contiguous()
+    if I > J:                                   # the kernel's 64 x 128 tile wants the rank-thin operand on the left
+        return _gemm_tn(q, p, alpha).t().contiguous()
     lib = _lib.load()
     out = torch.empty(I, J, dtype=torch.float32, device=p.device)
     nbytes = lib.spq_gemm_f32_tn_workspace_bytes(M, I, J)
