@@ -18,6 +18,7 @@ PATH_AUTO, PATH_F32, PATH_F16X2, PATH_U8X2, PATH_F16X3 = 0, 1, 2, 3, 4
 LOG_DIRECT = 2
 QTYPE_CODE = {"minmax": MINMAX, "log": LOG}            # part1 quantizers
 QTYPE_CODE_CPT = {"minmax": MINMAX, "log": LOG_DIRECT}  # part2 quantizers (log without the level round trip)
+QTYPE_ANY = {"minmax": MINMAX, "log": LOG, "log_direct": LOG_DIRECT}
 
 _lib = None
 _p = C.c_void_p

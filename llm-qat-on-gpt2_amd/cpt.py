@@ -1,0 +1,566 @@
+"""``CPTLinear`` (cyclic-precision linear layer) and its quantizer on the HIP kernels.
+
+Host-side mirror of the reference's ``part2_cyclic_precision_training``: ``quantization.py:14-291``
+(``GradientQuantizer``, ``LearnableFakeQuantize`` with per-bit-width scale dictionaries) and ``cpt_model.py:10-114``
+(``LoRAAdapter``, ``CPTLinear``) -- same constructors, attribute names, state-dict keys and error behaviour, so the
+classes drop into ``cpt_model.py`` in place of its own.  SURVEY.md §8 row f3.
+
+The operator differs from part1's in one way that matters to the kernels: the LoRA branch consumes the *quantized*
+input (cpt_model.py:112), so both terms share their left operand and the layer is ONE quantized contraction
+
+    y = FQ(x) . (FQ(W) + s FQ(B) FQ(A)^T)^T + bias
+
+-- the rank-r update is folded into the weight (0.2 % of the FLOPs) and the result goes through the same prepared-limb
+f16 MFMA contraction as part1's base term, with no LoRA stages at all.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .fake_quantize import LearnableFakeQuantize as _Part1FakeQuantize
+from .fake_quantize import fake_quantize
+from .sp_linear import _LimbGemm, _gemm_nt, _gemm_tn, _ones, _limb_scale
+
+
+class GradientQuantizer(torch.autograd.Function):
+    """quantization.py:14-26: identity forward; the gradient is fake-quantized by ``quantizer`` while that quantizer is
+    collecting statistics or calibrated at its bit-width."""
+
+    @staticmethod
+    def forward(ctx, input, quantizer):
+        ctx.quantizer = quantizer
+        return input
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return quantize_gradient(grad_output, ctx.quantizer), None
+
+
+def quantize_gradient(grad, quantizer):
+    if quantizer is not None and quantizer.collecting_stats:
+        return quantizer(grad)
+    if quantizer is not None and (quantizer.num_bits in quantizer.calibrated_bits):
+        return quantizer(grad)
+    return grad
+
+
+class _MinMaxSTE(torch.autograd.Function):
+    """quantization_methods.py:3-21 (part2): un-masked straight-through."""
+
+    @staticmethod
+    def forward(ctx, input, scale, zero_point, num_bits, symmetric):
+        return fake_quantize(input, scale, zero_point, num_bits, "minmax", symmetric)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output.clone(), None, None, None, None
+
+
+class _LogSTE(torch.autograd.Function):
+    """quantization_methods.py:23-51 (part2): log2-domain levels dequantised directly; backward clamps to [-10, 10]."""
+
+    @staticmethod
+    def forward(ctx, input, log_min, log_range, num_bits, symmetric):
+        return fake_quantize(input, log_range, log_min, num_bits, "log_direct", symmetric)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return torch.clamp(grad_output, -10, 10), None, None, None, None
+
+
+class LearnableFakeQuantize(_Part1FakeQuantize):
+    """Drop-in for part2's class of the same name (quantization.py:28): scales and zero points live in dictionaries keyed by
+    bit-width, ``calibrated_bits`` says which are valid, and an uncalibrated width passes the input through unless the
+    module is training with gradients on.  Statistics and scale derivation reuse part1's kernels (same arithmetic)."""
+
+    def __init__(self, num_bits, channel_dim=0, quantizer_type='minmax', eps=1e-5, symmetric=True, per_channel=True,
+                 is_input=False):
+        nn.Module.__init__(self)
+        self.num_bits = max(1, min(num_bits, 32))
+        self.symmetric = symmetric
+        self.per_channel = per_channel
+        self.channel_dim = channel_dim if per_channel else None
+        self.quantizer_type = quantizer_type
+        self.eps = eps
+        self.is_input = is_input
+        self._update_quant_range()
+        self.scales = {}
+        self.zero_points = {}
+        self.calibrated_bits = set()
+        self.register_buffer('running_min', torch.zeros(1))
+        self.register_buffer('running_max', torch.zeros(1))
+        self.collecting_stats = False
+        self.num_batches_collected = 0
+        self.temp_min = None
+        self.temp_max = None
+        self._epoch = 0
+
+    # the views part1-style helpers (operand preparation, limb scale) read
+    @property
+    def scale(self):
+        return self.scales[self.num_bits]
+
+    @property
+    def zero_point(self):
+        return self.zero_points[self.num_bits]
+
+    @property
+    def calibrated(self):
+        return self.num_bits in self.calibrated_bits
+
+    def set_num_bits(self, value):                                             # :129-132: no reset, scales are per width
+        self.num_bits = max(1, min(value, 32))
+        self._update_quant_range()
+
+    def start_calibration(self):                                               # :142-146
+        self.collecting_stats = True
+        self.num_batches_collected = 0
+        self.temp_min = None
+        self.temp_max = None
+
+    def finish_calibration(self, debug=False):                                 # :148-180
+        if self.num_batches_collected > 0 and self.temp_min is not None:
+            dev = self.temp_min.device
+            with torch.no_grad():
+                self.running_min = self.temp_min.detach().clone()
+                self.running_max = self.temp_max.detach().clone()
+                scale = torch.empty_like(self.running_min)
+                zp = torch.empty_like(self.running_min)
+                _lib.require_gpu(self.running_min, "calibration statistics")
+                with torch.cuda.device(dev):
+                    rc = _lib.load().spq_finish_scale(
+                        self.running_min.data_ptr(), self.running_max.data_ptr(), self.running_min.numel(),
+                        int(self.num_bits), _lib.QTYPE_CODE_CPT[self.quantizer_type], 1 if self.symmetric else 0,
+                        float(torch.tensor(self.eps, dtype=torch.float32)), scale.data_ptr(), zp.data_ptr(),
+                        _lib.stream_ptr(dev))
+                _lib.check(rc, "spq_finish_scale")
+                self.scales[self.num_bits] = scale
+                self.zero_points[self.num_bits] = zp
+            self.calibrated_bits.add(self.num_bits)
+            self._epoch += 1
+        self.collecting_stats = False
+        self.temp_min = None
+        self.temp_max = None
+
+    # ---- checkpoint format (quantization.py:51-127): extra keys '_scales_{b}', '_zero_points_{b}', '_calibrated_bits'
+    def state_dict(self, *args, destination=None, prefix='', keep_vars=False, **kwargs):
+        state = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars, **kwargs)
+        for bits, t in self.scales.items():
+            state[f'{prefix}_scales_{bits}'] = t if keep_vars else t.clone()
+        for bits, t in self.zero_points.items():
+            state[f'{prefix}_zero_points_{bits}'] = t if keep_vars else t.clone()
+        if self.calibrated_bits:
+            state[f'{prefix}_calibrated_bits'] = list(self.calibrated_bits)
+        return state
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        self.scales, self.zero_points, self.calibrated_bits = {}, {}, set()
+        dev = self.running_min.device
+        consumed = []
+        for key in list(state_dict.keys()):
+            if not key.startswith(prefix):
+                continue
+            suffix = key[len(prefix):]
+            if suffix.startswith('_scales_') or suffix.startswith('_zero_points_'):
+                kind = '_scales_' if suffix.startswith('_scales_') else '_zero_points_'
+                try:
+                    bits = int(suffix[len(kind):])
+                except ValueError:
+                    continue
+                (self.scales if kind == '_scales_' else self.zero_points)[bits] = state_dict[key].clone().to(dev)
+                if kind == '_scales_':
+                    self.calibrated_bits.add(bits)
+                consumed.append(key)
+            elif suffix == '_calibrated_bits':
+                if isinstance(state_dict[key], list):
+                    self.calibrated_bits = set(state_dict[key])
+                consumed.append(key)
+        for key in consumed:
+            del state_dict[key]
+        sk, zk = prefix + 'scale', prefix + 'zero_point'                      # part1-style checkpoints (:97-107)
+        if sk in state_dict and zk in state_dict:
+            self.scales[self.num_bits] = state_dict[sk].clone().to(dev)
+            self.zero_points[self.num_bits] = state_dict[zk].clone().to(dev)
+            self.calibrated_bits.add(self.num_bits)
+            del state_dict[sk], state_dict[zk]
+        for name in ('running_min', 'running_max'):
+            key = prefix + name
+            if key in state_dict:
+                incoming = state_dict[key]
+                if self.is_input and incoming.dim() == 3 and incoming.shape[1] > 1:      # :112-122
+                    take_min = self.quantizer_type != 'log' and 'min' in name
+                    incoming = incoming.min(dim=1, keepdim=True)[0] if take_min else incoming.max(dim=1, keepdim=True)[0]
+                    state_dict[key] = incoming
+                getattr(self, name).resize_as_(incoming)
+        nn.Module._load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                        error_msgs)
+        self._epoch += 1
+
+    def _apply(self, fn, *args, **kwargs):
+        """``.to(device)`` / ``.cuda()`` must carry the scale dictionaries along (they are not buffers)."""
+        out = super()._apply(fn, *args, **kwargs)
+        self.scales = {b: fn(t) for b, t in self.scales.items()}
+        self.zero_points = {b: fn(t) for b, t in self.zero_points.items()}
+        return out
+
+    # ---- forward (quantization.py:249-291)
+    def active(self) -> bool:
+        """True when ``forward`` quantizes (width below 32, not collecting, calibrated at this width)."""
+        return self.num_bits < 32 and not self.collecting_stats and self.num_bits in self.calibrated_bits
+
+    def forward(self, x):
+        if self.num_bits >= 32:
+            return x
+        if self.collecting_stats:
+            self._collect_statistics_batch(x)
+            return x
+        if self.num_bits not in self.calibrated_bits:
+            if self.training and torch.is_grad_enabled():
+                raise RuntimeError(
+                    f"FATAL: Quantizer not calibrated for {self.num_bits}-bit precision during training!\n"
+                    f"  Calibrated bits: {self.calibrated_bits}\n"
+                    f"  Available scales: {list(self.scales.keys())}\n"
+                    f"  Available zero_points: {list(self.zero_points.keys())}\n"
+                    f"  This indicates a bug in the calibration logic.\n"
+                    f"  Training cannot proceed with uncalibrated quantizers.")
+            return x
+        scale, zero_point = self.scales[self.num_bits], self.zero_points[self.num_bits]
+        if self.quantizer_type == 'minmax':
+            return _MinMaxSTE.apply(x, scale, zero_point, self.num_bits, self.symmetric)
+        elif self.quantizer_type == 'log':
+            return _LogSTE.apply(x, zero_point, scale, self.num_bits, self.symmetric)
+        raise ValueError(f"Unknown quantizer type: {self.quantizer_type}. Supported types: 'minmax', 'log'")
+
+    def quantize_levels(self, x):
+        if not self.calibrated:
+            raise RuntimeError(f"Quantizer not calibrated at {self.num_bits} bits")
+        qt = "log_direct" if self.quantizer_type == "log" else self.quantizer_type
+        return fake_quantize(x, self.scale, self.zero_point, self.num_bits, qt, self.symmetric, want_levels=True)[1]
+
+
+class LoRAAdapter(nn.Module):
+    """cpt_model.py:10-36: one adapter shared by every precision; ``lora_B`` is ``[out, rank]``."""
+
+    def __init__(self, in_features, out_features, rank=16, alpha=32, num_bits=8, quantizer_type='log', gradient_bits=8):
+        super().__init__()
+        self.rank = rank
+        self.alpha = alpha
+        self.scaling = alpha / rank if rank > 0 else 1.0
+        if rank > 0:
+            self.lora_A = nn.Parameter(torch.empty(in_features, rank))
+            nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))
+            self.lora_B = nn.Parameter(torch.zeros(out_features, rank))
+            self.grad_quantizer_A = LearnableFakeQuantize(num_bits=gradient_bits, quantizer_type='minmax', channel_dim=0,
+                                                          per_channel=True)
+            self.grad_quantizer_B = LearnableFakeQuantize(num_bits=gradient_bits, quantizer_type='minmax', channel_dim=0,
+                                                          per_channel=True)
+        else:
+            self.lora_A = None
+            self.lora_B = None
+            self.grad_quantizer_A = None
+            self.grad_quantizer_B = None
+        self.calibration_mode = False
+
+
+def _ste(grad, q):
+    """Backward of the quantization function ``q`` applied in the forward: identity when it passed its input through."""
+    if q is not None and q.active() and q.quantizer_type == 'log':
+        return torch.clamp(grad, -10, 10)
+    return grad
+
+
+class _QuantGemm:
+    """y = FQ(x) . w_eff^T + bias for an fp32 ``w_eff`` [N, K] that already holds every weight-side term: prepares the
+    limbs (spq_prepare_f16x2, identity weight quantizer, input scale folded in for SPQ_PATH_F16X2) and runs the fused
+    forward with r = 0.  Optionally returns FQ(x) . down^T from the activation pass (``down`` [r, K])."""
+
+    def __init__(self):
+        self.key = None
+        self.sig = None
+
+    def path_for(self, q, N, quantize):
+        if not quantize:
+            return _lib.PATH_F32                       # nothing to quantize (statistics pass / uncalibrated width)
+        if N % 4 != 0:
+            return _lib.PATH_F32
+        if q.quantizer_type == 'minmax' and q.symmetric and 2 <= q.num_bits <= 12:
+            return _lib.PATH_F16X2
+        return _lib.PATH_F16X3 if q.num_bits <= 24 else _lib.PATH_F32
+
+    def __call__(self, x2, w_eff, bias, q, quantize, down=None, sig=None, gemm_events=None):
+        M, K = x2.shape
+        N = w_eff.shape[0]
+        dev = x2.device
+        lib = _lib.load()
+        path = self.path_for(q, N, quantize)
+        r, t, down_p = 0, None, None
+        if down is not None:
+            r = down.shape[0]
+            if r > 128 and path != _lib.PATH_F32:
+                path = _lib.PATH_F32
+            r_pad = (r + 63) // 64 * 64
+            down_p = down.contiguous()
+            if r_pad != r:
+                down_p = torch.zeros(r_pad, K, dtype=torch.float32, device=dev)
+                down_p[:r] = down
+            t = torch.empty(M, r, dtype=torch.float32, device=dev)
+        y = torch.empty(M, N, dtype=torch.float32, device=dev)
+        st = _lib.stream_ptr(dev)
+        sx = q.scale if quantize else None
+        zx = q.zero_point if quantize else None
+        if quantize and sx.numel() not in (1, K):
+            raise RuntimeError(f"input scale of shape {tuple(sx.shape)} does not fit input features {K}")
+        x_pc = 1 if (quantize and sx.numel() > 1) else 0
+        ws = _lib.workspace(dev, lib.spq_fwd_workspace_bytes(M, K, N, r, path))
+        limb_scale = None
+        self.path = path
+        with torch.cuda.device(dev):
+            if path == _lib.PATH_F32:
+                w_ptr, rowscale = w_eff.data_ptr(), None
+            else:
+                if self.key != (N, K, dev):
+                    self.w = torch.empty(lib.spq_prep_f16x2_bytes(N, K, 0), dtype=torch.uint8, device=dev)
+                    self.rowscale = torch.empty((N + 127) // 128 * 128, dtype=torch.float32, device=dev)
+                    self.key, self.sig = (N, K, dev), None
+                one = _ones(dev)
+                fold = sx if path == _lib.PATH_F16X2 else one
+                full_sig = None if sig is None else (sig, path, q._epoch, q.num_bits)
+                if full_sig is None or full_sig != self.sig:
+                    rc = lib.spq_prepare_f16x2(w_eff.data_ptr(), N, K, one.data_ptr(), one.data_ptr(), 0, 32, 0, 1,
+                                               None, 0, None, None, 0, 0, 0, 1, 0.0, None, None, None, 0, 0, 0, 1,
+                                               fold.data_ptr(), 1 if fold.numel() > 1 else 0, self.w.data_ptr(),
+                                               self.w.numel(), self.rowscale.data_ptr(), None, st)
+                    _lib.check(rc, "spq_prepare_f16x2(cpt)")
+                    self.sig = full_sig
+                w_ptr, rowscale = self.w.data_ptr(), self.rowscale
+                if path == _lib.PATH_F16X3:
+                    limb_scale = _limb_scale(q)
+            args = _lib.FwdArgs(
+                M=M, K=K, N=N, r=r, bits=int(q.num_bits) if quantize else 32,
+                qtype=_lib.QTYPE_CODE_CPT.get(q.quantizer_type, 0), symmetric=1 if q.symmetric else 0,
+                quantize_input=1 if quantize else 0, x_per_channel=x_pc, path=path, x=x2.data_ptr(), sx=_lib.ptr(sx),
+                zx=_lib.ptr(zx), x_limb_scale=_lib.ptr(limb_scale), w_prep=w_ptr, w_rowscale=_lib.ptr(rowscale),
+                bias=_lib.ptr(bias), a_prep=_lib.ptr(down_p), b_prep=None, lora_scaling=0.0, y=y.data_ptr(),
+                workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
+                ev_gemm_begin=gemm_events[0] if gemm_events else None, ev_gemm_end=gemm_events[1] if gemm_events else None,
+                t_out=_lib.ptr(t), lora_on_fq_input=1)
+            rc = lib.spq_linear_lora_fwd(ctypes.byref(args), st)
+            _lib.check(rc, "spq_linear_lora_fwd(cpt)")
+        return y if down is None else (y, t)
+
+
+def _sig(t):
+    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape))
+
+
+class CPTLinear(nn.Module):
+    """Drop-in for ``cpt_model.CPTLinear`` (cpt_model.py:38-114)."""
+
+    def __init__(self, in_features, out_features, bit_widths=[4, 6, 8], quantizer_per_bit=None, gradient_bits=8,
+                 bias=True, shared_lora_rank=16, shared_lora_alpha=32):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.bit_widths = bit_widths
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+        self.shared_lora = LoRAAdapter(in_features, out_features, rank=shared_lora_rank, alpha=shared_lora_alpha,
+                                       num_bits=8, quantizer_type='log', gradient_bits=gradient_bits)
+        if quantizer_per_bit is None:
+            quantizer_per_bit = {bits: 'log' for bits in bit_widths}
+        self.lora_weight_quantizers = nn.ModuleDict()
+        for bits in bit_widths:
+            self.lora_weight_quantizers[f'{bits}bit'] = LearnableFakeQuantize(
+                num_bits=bits, quantizer_type=quantizer_per_bit.get(bits, 'log'), channel_dim=1, per_channel=True)
+        max_bits = max([b for b in bit_widths if b < 32]) if any(b < 32 for b in bit_widths) else 8
+        max_quant_type = quantizer_per_bit.get(max_bits, 'log')
+        self.quantizer_weight = LearnableFakeQuantize(num_bits=max_bits, quantizer_type=max_quant_type, channel_dim=0,
+                                                      per_channel=True)
+        self.quantizer_input = LearnableFakeQuantize(num_bits=max_bits, quantizer_type=max_quant_type, channel_dim=-1,
+                                                     per_channel=True, is_input=True)
+        self.current_bits = max(bit_widths)
+        self.calibration_mode = False
+        self._gemm = _QuantGemm()
+        self._bwd_gemm = None
+        self._gemm_events = None
+        self._last_path = None
+        self.cache_operands = True          # eval mode: reuse the prepared weight while W, A, B and the scales are unchanged
+
+    def set_precision(self, num_bits: int):
+        if num_bits not in self.bit_widths:
+            raise ValueError(f"Precision {num_bits} not in widths {self.bit_widths}")
+        self.current_bits = num_bits
+        if num_bits < 32:
+            self.quantizer_weight.set_num_bits(num_bits)
+            self.quantizer_input.set_num_bits(num_bits)
+
+    # ---- weight side: FQ(W) + s FQ(B) FQ(A)^T, every quantizer in whatever state it is in (cpt_model.py:96-113)
+    def _lora_factors(self):
+        ql = self.lora_weight_quantizers[f'{self.current_bits}bit']
+        with torch.no_grad():
+            aq = ql(self.shared_lora.lora_A.detach())
+            bq = ql(self.shared_lora.lora_B.detach())
+        return ql, aq, bq
+
+    def _effective_weight(self, use_lora):
+        with torch.no_grad():
+            wq = self.quantizer_weight(self.linear.weight.detach())
+            if not use_lora:
+                return wq.contiguous(), None, None, None
+            ql, aq, bq = self._lora_factors()
+            return torch.addmm(wq, bq, aq.t(), alpha=float(self.shared_lora.scaling)), ql, aq, bq
+
+    def _weights_sig(self, use_lora):
+        lo = self.shared_lora
+        sig = [_sig(self.linear.weight), self.current_bits, use_lora, self.quantizer_weight._epoch,
+               self.quantizer_weight.collecting_stats]
+        if use_lora:
+            ql = self.lora_weight_quantizers[f'{self.current_bits}bit']
+            sig += [_sig(lo.lora_A), _sig(lo.lora_B), ql._epoch, ql.collecting_stats, ql.num_bits]
+        return tuple(sig)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.current_bits == 32:
+            return F.linear(x, self.linear.weight, self.linear.bias)
+        if not x.is_cuda:
+            raise RuntimeError(f"llm_qat_on_gpt2_amd: CPTLinear input is on '{x.device}'. The fake-quant path runs only as HIP "
+                               "kernels on a gfx950 (MI355X) device; there is no CPU fallback.")
+        _lib.check_device(x.device)
+        use_lora = (not self.calibration_mode) and self.shared_lora.lora_A is not None
+        lo = self.shared_lora
+        needs_grad = torch.is_grad_enabled() and (
+            x.requires_grad or self.linear.weight.requires_grad
+            or (self.linear.bias is not None and self.linear.bias.requires_grad)
+            or (use_lora and (lo.lora_A.requires_grad or lo.lora_B.requires_grad)))
+        if needs_grad:
+            return _CPTLinearFunction.apply(x, self.linear.weight, self.linear.bias, lo.lora_A if use_lora else None,
+                                            lo.lora_B if use_lora else None, self, use_lora)
+        with torch.no_grad():
+            return self._forward_fused(x, use_lora)
+
+    def _forward_fused(self, x, use_lora, want_t=False):
+        qi = self.quantizer_input
+        if qi.num_bits < 32 and qi.collecting_stats:
+            qi._collect_statistics_batch(x)                                  # quantization.py:252-254
+            quantize = False
+        elif qi.num_bits < 32 and qi.num_bits not in qi.calibrated_bits:
+            qi(x)                                                            # raises in training, passes through in eval
+            quantize = False
+        else:
+            quantize = qi.num_bits < 32
+        if quantize and qi.quantizer_type not in _lib.QTYPE_CODE_CPT:
+            raise ValueError(f"Unknown quantizer type: {qi.quantizer_type}. Supported types: 'minmax', 'log'")
+        x2 = x.detach().contiguous().float().view(-1, self.in_features)
+        lead = tuple(x.shape[:-1])
+        sig = self._weights_sig(use_lora) if (self.cache_operands and not self.training) else None
+        reuse = sig is not None and self._gemm.sig is not None and self._gemm.sig[0] == sig and not want_t
+        if reuse:
+            w_eff, aq = self._w_eff_cached, None
+        else:
+            w_eff, ql, aq, bq = self._effective_weight(use_lora)
+            self._w_eff_cached = w_eff
+        if x2.shape[0] == 0:
+            return torch.empty(*lead, self.out_features, dtype=torch.float32, device=x.device)
+        down = aq.t().contiguous() if (want_t and use_lora) else None
+        out = self._gemm(x2, w_eff, self.linear.bias, qi, quantize, down=down, sig=sig, gemm_events=self._gemm_events)
+        self._last_path = self._gemm.path
+        if down is not None:
+            y, t = out
+            return y.view(*lead, self.out_features), t
+        return out.view(*lead, self.out_features)
+
+
+class _CPTLinearFunction(torch.autograd.Function):
+    """Fused forward with the reference's backward (cpt_model.py:96-113 under autograd):
+
+        d/dx  = STE_in( g . W_eff )                      W_eff = FQ(W) + s FQ(B) FQ(A)^T          (one limb contraction)
+        d/dA  = STE_l( GQ_A( s * FQ(x)^T . (g . FQ(B)) ) )      d/dB = STE_l( GQ_B( s * g^T . (FQ(x) . FQ(A)) ) )
+        d/dW  = STE_w( g^T . FQ(x) )                     d/dbias = sum_m g
+
+    STE = identity (minmax) / clamp to [-10, 10] (log) / identity for a quantizer that passed its input through;
+    GQ = GradientQuantizer (quantization.py:14-26)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, A, B, module, use_lora):
+        with torch.no_grad():
+            out = module._forward_fused(x, use_lora, want_t=use_lora)
+        y, t = out if use_lora else (out, None)
+        ctx.module, ctx.use_lora = module, use_lora
+        ctx.save_for_backward(x, t)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        module, use_lora = ctx.module, ctx.use_lora
+        x, t = ctx.saved_tensors
+        K, N = module.in_features, module.out_features
+        need_x, need_W, need_b, need_A, need_B = ctx.needs_input_grad[:5]
+        qi, qw, lo = module.quantizer_input, module.quantizer_weight, module.shared_lora
+        gx = gW = gb = gA = gB = None
+        with torch.no_grad():
+            g2 = g.contiguous().float().reshape(-1, N)
+            x2 = x.detach().contiguous().float().reshape(-1, K)
+            s = float(lo.scaling)
+            w_eff, ql, aq, bq = module._effective_weight(use_lora)
+            gt = None
+            want_gt = use_lora and need_A
+            if need_x:
+                w_t = w_eff.t().contiguous()                                   # [K, N]
+                if _LimbGemm.supported(K, N):
+                    if module._bwd_gemm is None:
+                        module._bwd_gemm = _LimbGemm()
+                    if want_gt and bq.shape[1] <= 128:
+                        gx, gt = module._bwd_gemm(g2, w_t, down=bq.t().contiguous())   # g . FQ(B) rides the activation pass
+                    else:
+                        gx = module._bwd_gemm(g2, w_t)
+                else:
+                    gx = _gemm_nt(g2, w_t)
+                gx = _ste(gx, qi).view(x.shape)
+            if want_gt and gt is None:
+                gt = _gemm_nt(g2, bq.t().contiguous())                         # [M, r]
+            xq = None
+            if (use_lora and need_A) or need_W:
+                xq = qi(x2).reshape(-1, K) if qi.active() else x2      # a keep-dim [1,1,K] scale lifts 2-D to 3-D
+            if use_lora and need_A:
+                gA = _ste(quantize_gradient(_gemm_tn(xq, gt, s), lo.grad_quantizer_A), ql)
+            if use_lora and need_B:
+                gB = _ste(quantize_gradient(_gemm_tn(g2, t, s), lo.grad_quantizer_B), ql)
+            if need_W:
+                gW = _ste(g2.t() @ xq, qw)
+            if need_b:
+                gb = g2.sum(dim=0)
+        return gx, gW, gb, gA, gB, None, None
+
+
+def calibrate_cpt_layer(layer: CPTLinear, bits: int, batches, group=None, comm=None) -> int:
+    """calibration.py:17-88 and :161-203 on one layer, with the data-parallel merge of the input statistics
+    (see calibration.allreduce_calibration_stats).  Returns the element count of the all-reduce."""
+    from .calibration import allreduce_calibration_stats
+    if bits >= 32:
+        return 0
+    layer.set_precision(bits)
+    qw = layer.quantizer_weight
+    qw.set_num_bits(bits); qw.start_calibration()
+    with torch.no_grad():
+        qw(layer.linear.weight.data)
+    qw.finish_calibration(debug=False)
+    qi = layer.quantizer_input
+    qi.set_num_bits(bits); qi.start_calibration()
+    layer.calibration_mode = True
+    try:
+        with torch.no_grad():
+            for xb in batches:
+                layer(xb)
+    finally:
+        layer.calibration_mode = False
+    exchanged = allreduce_calibration_stats([qi], group, comm)
+    qi.finish_calibration(debug=False)
+    ql = layer.lora_weight_quantizers[f'{bits}bit']
+    ql.set_num_bits(bits); ql.start_calibration()
+    with torch.no_grad():
+        ql(layer.shared_lora.lora_A); ql(layer.shared_lora.lora_B)
+    ql.finish_calibration(debug=False)
+    return exchanged

@@ -57,7 +57,7 @@ def fake_quantize(x, scale, zero_point, num_bits, qtype, symmetric, want_levels=
     if x.numel():
         with torch.cuda.device(x.device):
             rc = _lib.load().spq_fakequant(x.data_ptr(), outer, chan, inner, scale.data_ptr(), zero_point.data_ptr(),
-                                           0 if ax is None else 1, int(num_bits), _lib.QTYPE_CODE[qtype],
+                                           0 if ax is None else 1, int(num_bits), _lib.QTYPE_ANY[qtype],
                                            1 if symmetric else 0, out.data_ptr(), _lib.ptr(levels), 4,
                                            _lib.stream_ptr(x.device))
         _lib.check(rc, "spq_fakequant")

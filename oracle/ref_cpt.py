@@ -1,0 +1,158 @@
+"""CPU oracle for part2's ``CPTLinear.forward``.  TEST INFRASTRUCTURE ONLY.
+
+Same rules as ``oracle/ref_cpu.py``: plain torch CPU ops in the reference's order, imported by ``tests/`` only (and by
+``tests/golden/make_golden_cpt.py``, which pins it bit-for-bit against the imported reference in the build container).
+Paths cited are relative to ``part2_cyclic_precision_training/``.
+
+Differences from part1's operator that matter here (cpt_model.py:92-114):
+  * the LoRA branch consumes the *quantized* input:  out + (x_q @ FQ(A) @ FQ(B).T) * scaling
+  * ``lora_B`` is stored ``[N, r]`` and used transposed; A and B share ONE quantizer per bit-width (``channel_dim=1`` on
+    both, so one scale per rank column), calibrated on A then B (calibration.py:161-203)
+  * the log quantizer dequantises ``q/(2n) + 0.5`` directly (quantization_methods.py:36-40), without part1's
+    ``* (2^b-1) / (2^b-1)`` round trip
+  * quantizers keep a dict of scales per bit-width and pass x through un-quantized when the active width is not
+    calibrated and gradients are off (quantization.py:257-272)
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ref_cpu as R
+
+LOG_FN_EPS = 1e-5  # quantization_methods.py:26
+
+
+def log_fakequant_direct(x, log_min, log_range, bits: int, symmetric: bool = True) -> torch.Tensor:
+    """quantization_methods.py:23-47 (levels as part1's, see ref_cpu.log_levels; dequantisation without the round trip)."""
+    zero_mask = torch.abs(x) < LOG_FN_EPS                                      # :31
+    sgn = torch.sign(x)                                                        # :32
+    q, _ = R.log_levels(x, log_min, log_range, bits, symmetric)                # :33-39 / :42-43 (same ops as part1)
+    if symmetric:
+        n = 2 ** (bits - 1) - 1
+        qn = q / (2 * n) + 0.5                                                 # :40
+    else:
+        qn = q / (2 ** bits - 1)                                               # :44
+    out = torch.pow(2, qn * log_range + log_min) * sgn                         # :46
+    return torch.where(zero_mask, torch.zeros_like(x), out)                    # :47
+
+
+class CPTQuantState:
+    """``LearnableFakeQuantize`` of part2 (quantization.py:28-291) as data: per-bit-width scale dictionaries."""
+
+    def __init__(self, bits: int, qtype: str = "minmax", channel_dim: Optional[int] = 0, per_channel: bool = True,
+                 symmetric: bool = True, eps: float = 1e-5):
+        self.bits = max(1, min(bits, 32))                                      # :32
+        self.qtype, self.per_channel, self.symmetric, self.eps = qtype, per_channel, symmetric, eps
+        self.channel_dim = channel_dim if per_channel else None                # :35
+        self.scales: Dict[int, torch.Tensor] = {}
+        self.zero_points: Dict[int, torch.Tensor] = {}
+        self.calibrated_bits = set()
+        self.running_min = torch.zeros(1)
+        self.running_max = torch.zeros(1)
+        self.collecting = False
+        self.nbatches = 0
+        self.tmin = self.tmax = None
+
+    def set_num_bits(self, bits: int):                                         # :129-132
+        self.bits = max(1, min(bits, 32))
+
+    def start(self):                                                           # :142-146
+        self.collecting, self.nbatches = True, 0
+        self.tmin = self.tmax = None
+
+    def observe(self, x: torch.Tensor):                                        # :214-247 (same statistics as part1)
+        st = R.QuantState(self.bits, self.qtype, self.channel_dim, self.per_channel, self.symmetric, self.eps)
+        st.nbatches, st.tmin, st.tmax = self.nbatches, self.tmin, self.tmax
+        st.observe(x)
+        self.nbatches, self.tmin, self.tmax = st.nbatches, st.tmin, st.tmax
+
+    def finish(self):                                                          # :148-180
+        if self.nbatches > 0 and self.tmin is not None:
+            self.running_min, self.running_max = self.tmin.clone(), self.tmax.clone()
+            scale, zp = R.finish_scale(self.running_min, self.running_max, self.bits, self.qtype, self.symmetric, self.eps)
+            self.scales[self.bits], self.zero_points[self.bits] = scale, zp
+            self.calibrated_bits.add(self.bits)
+        self.collecting = False
+        self.tmin = self.tmax = None
+
+    def __call__(self, x, training_with_grad: bool = False):                   # :249-285
+        if self.bits >= 32:
+            return x
+        if self.collecting:
+            self.observe(x)
+            return x
+        if self.bits not in self.calibrated_bits:
+            if training_with_grad:
+                raise RuntimeError(f"FATAL: Quantizer not calibrated for {self.bits}-bit precision during training!")
+            return x
+        s, z = self.scales[self.bits], self.zero_points[self.bits]
+        if self.qtype == "minmax":
+            return R.minmax_fakequant(x, s, z, self.bits, self.symmetric)
+        if self.qtype == "log":
+            return log_fakequant_direct(x, z, s, self.bits, self.symmetric)
+        raise ValueError(f"Unknown quantizer type: {self.qtype}. Supported types: 'minmax', 'log'")
+
+
+class OracleCPTLayer:
+    """cpt_model.py:38-114 as data + forward."""
+
+    def __init__(self, W, bias, A, B_nr, bit_widths, quantizer_per_bit=None, rank=16, alpha=32.0):
+        self.W, self.bias, self.A, self.B = W, bias, A, B_nr
+        self.bit_widths = list(bit_widths)
+        self.scaling = alpha / rank if rank > 0 else 1.0                       # :19
+        qpb = quantizer_per_bit or {b: "log" for b in bit_widths}              # :57-58
+        self.q_lora = {b: CPTQuantState(b, qpb.get(b, "log"), 1, True) for b in bit_widths}       # :60-68
+        student = [b for b in bit_widths if b < 32]
+        max_bits = max(student) if student else 8                              # :70
+        mq = qpb.get(max_bits, "log")
+        self.q_w = CPTQuantState(max_bits, mq, 0, True)                        # :73-75
+        self.q_in = CPTQuantState(max_bits, mq, -1, True)                      # :76-78
+        self.current_bits = max(bit_widths)                                    # :80
+        self.calibration_mode = False
+
+    def set_precision(self, bits: int):                                        # :83-89
+        if bits not in self.bit_widths:
+            raise ValueError(f"Precision {bits} not in widths {self.bit_widths}")
+        self.current_bits = bits
+        if bits < 32:
+            self.q_w.set_num_bits(bits)
+            self.q_in.set_num_bits(bits)
+
+    def calibrate(self, bits: int, batches):
+        """calibration.py:17-88 on one layer (weights on themselves, inputs through LoRA-free forwards), then
+        calibration.py:161-203 (the shared LoRA quantizer sees A, then B)."""
+        if bits >= 32:
+            return
+        self.set_precision(bits)
+        self.q_w.set_num_bits(bits); self.q_w.start(); self.q_w(self.W); self.q_w.finish()
+        self.q_in.set_num_bits(bits); self.q_in.start()
+        self.calibration_mode = True
+        for xb in batches:
+            self.forward(xb)
+        self.calibration_mode = False
+        self.q_in.finish()
+        ql = self.q_lora[bits]
+        ql.set_num_bits(bits); ql.start(); ql(self.A); ql(self.B); ql.finish()
+
+    def forward(self, x):                                                      # :91-114
+        if self.current_bits == 32:
+            return F.linear(x, self.W, self.bias)
+        xq = self.q_in(x)
+        wq = self.q_w(self.W)
+        out = F.linear(xq, wq, self.bias)
+        if self.calibration_mode:
+            return out
+        ql = self.q_lora[self.current_bits]
+        aq, bq = ql(self.A), ql(self.B)
+        lora = xq @ aq @ bq.T
+        return out + lora * self.scaling
+
+
+def make_cpt_workload(M, K, N, r, seed=0, batch=1):
+    """Synthetic CPTLinear tensors in the style of ref_cpu.make_workload; lora_B [N, r] non-zero (the reference's zero
+    init, cpt_model.py:24, would make the branch trivially zero)."""
+    W, bias, A, B_rn, x0, x1 = R.make_workload(M, K, N, r, seed=seed, batch=batch)
+    return W, bias, A, B_rn.t().contiguous(), x0, x1
