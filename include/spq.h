@@ -213,6 +213,23 @@ int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const float* sw, con
                       int x_per_channel, void* w_prep, size_t w_prep_bytes, float* w_rowscale, float* a_prep,
                       spq_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Weight-side operand of part2's CPTLinear (part2_cyclic_precision_training/cpt_model.py:96-113).  Its LoRA branch
+ * consumes FQ(x) like the base term, so the whole layer is ONE contraction  y = FQ(x) . W_eff^T + bias  with
+ *   W_eff[n,k] = FQ_w(W)[n,k] + scaling * sum_j FQ_l(B)[n,j] * FQ_l(A)[k,j]       (W [N,K], A [K,r], B [N,r], r <= 64)
+ * FQ_l: the ONE quantizer part2 shares between A and B (channel_dim = 1: r or 1 parameters).  A quantizer that passes
+ * its input through (32 bit, uncalibrated width) is given as bits = 32.  Outputs: w_eff [N,K] fp32 (the operand of
+ * SPQ_PATH_F32 and of the backward), aq [K,r], bq [N,r], optionally aq_t = FQ(A)^T [ceil(r/64)*64, K] (the a_prep of a
+ * training forward that keeps FQ(x).FQ(A) via t_out + lora_on_fq_input), and for path F16X2 / F16X3 the limb planes
+ * w_prep + w_rowscale exactly as spq_prepare_f16x2 writes them (sx folded for F16X2; pass the input scale, or a
+ * one-element tensor holding 1.0 with x_per_channel = 0 for F16X3).
+ * ------------------------------------------------------------------------------------------------- */
+int spq_prepare_cpt(const float* W, int64_t N, int64_t K, const float* sw, const float* zw, int w_per_channel, int w_bits,
+                    int w_qtype, int w_symmetric, const float* A, const float* B, int64_t r, const float* sl,
+                    const float* zl, int l_per_channel, int l_bits, int l_qtype, int l_symmetric, float scaling,
+                    const float* sx, int x_per_channel, int path, void* w_prep, size_t w_prep_bytes, float* w_rowscale,
+                    float* w_eff, float* aq, float* bq, float* aq_t, spq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,8 @@ SIGNATURES = {
     "spq_dynamic_limb_scale": (_int, [_p, _i64, _p, _p, _sz, _p]),
     "spq_gemm_f32_tn_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "spq_gemm_f32_tn": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _f, _p, _p, _sz, _p]),
+    "spq_prepare_cpt": (_int, [_p, _i64, _i64, _p, _p, _int, _int, _int, _int, _p, _p, _i64, _p, _p, _int, _int, _int, _int, _f,
+                                _p, _int, _int, _p, _sz, _p, _p, _p, _p, _p, _p]),
     "spq_version": (_int, []),
     "spq_last_error": (C.c_char_p, []),
     "spq_device_arch": (_int, [C.c_char_p, _int]),

@@ -273,84 +273,130 @@ def _ste(grad, q):
     return grad
 
 
+def _qparams(q, dev):
+    """(scale ptr-holder, zero-point, per_channel, bits, qtype code, symmetric) of a quantizer as the C ABI wants them; a
+    quantizer that passes its input through (32 bit / width not calibrated) is the identity: bits = 32."""
+    if q is not None and q.active():
+        s, z = q.scale, q.zero_point
+        return s, z, 1 if s.numel() > 1 else 0, int(q.num_bits), _lib.QTYPE_CODE_CPT[q.quantizer_type], 1 if q.symmetric else 0
+    one = _ones(dev)
+    return one, one, 0, 32, 0, 1
+
+
 class _QuantGemm:
-    """y = FQ(x) . w_eff^T + bias for an fp32 ``w_eff`` [N, K] that already holds every weight-side term: prepares the
-    limbs (spq_prepare_f16x2, identity weight quantizer, input scale folded in for SPQ_PATH_F16X2) and runs the fused
-    forward with r = 0.  Optionally returns FQ(x) . down^T from the activation pass (``down`` [r, K])."""
+    """y = FQ(x) . W_eff^T + bias, W_eff = FQ(W) + s FQ(B) FQ(A)^T: ``prepare`` builds W_eff and its limb planes in one C
+    call (spq_prepare_cpt), ``run`` is the fused forward with r = 0 -- or with the LoRA-down product FQ(x) . FQ(A) riding
+    the activation pass when a training step wants it for d/dB."""
 
     def __init__(self):
         self.key = None
         self.sig = None
+        self.path = None
 
-    def path_for(self, q, N, quantize):
-        if not quantize:
+    @staticmethod
+    def path_for(q, N, quantize):
+        if not quantize or N % 4 != 0:
             return _lib.PATH_F32                       # nothing to quantize (statistics pass / uncalibrated width)
-        if N % 4 != 0:
-            return _lib.PATH_F32
         if q.quantizer_type == 'minmax' and q.symmetric and 2 <= q.num_bits <= 12:
             return _lib.PATH_F16X2
         return _lib.PATH_F16X3 if q.num_bits <= 24 else _lib.PATH_F32
 
-    def __call__(self, x2, w_eff, bias, q, quantize, down=None, sig=None, gemm_events=None):
+    def _buffers(self, N, K, r, dev):
+        if self.key != (N, K, r, dev):
+            lib = _lib.load()
+            self.w = torch.empty(lib.spq_prep_f16x2_bytes(N, K, 0), dtype=torch.uint8, device=dev)
+            self.rowscale = torch.empty((N + 127) // 128 * 128, dtype=torch.float32, device=dev)
+            self.w_eff = torch.empty(N, K, dtype=torch.float32, device=dev)
+            self.aq = torch.empty(K, max(r, 1), dtype=torch.float32, device=dev)
+            self.bq = torch.empty(N, max(r, 1), dtype=torch.float32, device=dev)
+            self.aq_t = torch.empty((max(r, 1) + 63) // 64 * 64, K, dtype=torch.float32, device=dev)
+            self.key, self.sig = (N, K, r, dev), None
+
+    def prepare(self, layer, use_lora, path, qi, quantize, want_aq_t=False, sig=None):
+        """Weight-side operands for ``path``; every quantizer in whatever state it is in (cpt_model.py:96-110)."""
+        W = layer.linear.weight.detach()
+        N, K = W.shape
+        dev = W.device
+        lo = layer.shared_lora
+        r = lo.rank if use_lora else 0
+        self._buffers(N, K, r, dev)
+        qw = layer.quantizer_weight
+        ql = layer.lora_weight_quantizers[f'{layer.current_bits}bit'] if use_lora else None
+        lib = _lib.load()
+        st = _lib.stream_ptr(dev)
+        one = _ones(dev)
+        fold = qi.scale if (path == _lib.PATH_F16X2) else one
+        fused = r <= 64 and not qw.collecting_stats and not (ql is not None and ql.collecting_stats) and W.is_contiguous()
+        with torch.no_grad(), torch.cuda.device(dev):
+            if fused:
+                sw, zw, w_pc, w_bits, w_qt, w_sym = _qparams(qw, dev)
+                sl, zl, l_pc, l_bits, l_qt, l_sym = _qparams(ql, dev)
+                if w_pc and sw.numel() != N:
+                    raise RuntimeError(f"weight scale of shape {tuple(sw.shape)} does not fit {N} output features")
+                if l_pc and sl.numel() != r:
+                    raise RuntimeError(f"LoRA scale of shape {tuple(sl.shape)} does not fit rank {r}")
+                A = lo.lora_A.detach().contiguous() if use_lora else None
+                B = lo.lora_B.detach().contiguous() if use_lora else None
+                rc = lib.spq_prepare_cpt(
+                    W.data_ptr(), N, K, sw.data_ptr(), zw.data_ptr(), w_pc, w_bits, w_qt, w_sym, _lib.ptr(A), _lib.ptr(B), r,
+                    sl.data_ptr(), zl.data_ptr(), l_pc, l_bits, l_qt, l_sym, float(lo.scaling) if use_lora else 0.0,
+                    fold.data_ptr(), 1 if fold.numel() > 1 else 0, path, self.w.data_ptr(), self.w.numel(),
+                    self.rowscale.data_ptr(), self.w_eff.data_ptr(), self.aq.data_ptr(), self.bq.data_ptr(),
+                    self.aq_t.data_ptr() if (want_aq_t and r) else None, st)
+                _lib.check(rc, "spq_prepare_cpt")
+            else:                                      # a quantizer is recording statistics, or rank > 64: module calls
+                wq = qw(W)
+                if use_lora:
+                    aq, bq = ql(lo.lora_A.detach()), ql(lo.lora_B.detach())
+                    self.aq.copy_(aq); self.bq.copy_(bq)
+                    torch.addmm(wq, bq, aq.t(), alpha=float(lo.scaling), out=self.w_eff)
+                    if want_aq_t:
+                        self.aq_t.zero_()
+                        self.aq_t[:r].copy_(aq.t())
+                else:
+                    self.w_eff.copy_(wq)
+                if path != _lib.PATH_F32:
+                    rc = lib.spq_prepare_f16x2(self.w_eff.data_ptr(), N, K, one.data_ptr(), one.data_ptr(), 0, 32, 0, 1,
+                                               None, 0, None, None, 0, 0, 0, 1, 0.0, None, None, None, 0, 0, 0, 1,
+                                               fold.data_ptr(), 1 if fold.numel() > 1 else 0, self.w.data_ptr(),
+                                               self.w.numel(), self.rowscale.data_ptr(), None, st)
+                    _lib.check(rc, "spq_prepare_f16x2(cpt)")
+        self.path, self.r = path, r
+        self.sig = None if sig is None else (sig, path, qi._epoch, qi.num_bits)
+
+    def run(self, x2, bias, q, quantize, want_t=False, gemm_events=None):
         M, K = x2.shape
-        N = w_eff.shape[0]
+        N = self.w_eff.shape[0]
         dev = x2.device
         lib = _lib.load()
-        path = self.path_for(q, N, quantize)
-        r, t, down_p = 0, None, None
-        if down is not None:
-            r = down.shape[0]
-            if r > 128 and path != _lib.PATH_F32:
-                path = _lib.PATH_F32
-            r_pad = (r + 63) // 64 * 64
-            down_p = down.contiguous()
-            if r_pad != r:
-                down_p = torch.zeros(r_pad, K, dtype=torch.float32, device=dev)
-                down_p[:r] = down
-            t = torch.empty(M, r, dtype=torch.float32, device=dev)
+        path = self.path
+        r = self.r if want_t else 0
+        if r > 128 or (r > 0 and path != _lib.PATH_F32 and r > 64):
+            raise RuntimeError("the LoRA-down product of the activation pass needs rank <= 64")
+        t = torch.empty(M, r, dtype=torch.float32, device=dev) if r else None
         y = torch.empty(M, N, dtype=torch.float32, device=dev)
         st = _lib.stream_ptr(dev)
         sx = q.scale if quantize else None
         zx = q.zero_point if quantize else None
         if quantize and sx.numel() not in (1, K):
             raise RuntimeError(f"input scale of shape {tuple(sx.shape)} does not fit input features {K}")
-        x_pc = 1 if (quantize and sx.numel() > 1) else 0
         ws = _lib.workspace(dev, lib.spq_fwd_workspace_bytes(M, K, N, r, path))
-        limb_scale = None
-        self.path = path
+        f32 = path == _lib.PATH_F32
+        limb_scale = _limb_scale(q) if path == _lib.PATH_F16X3 else None
+        args = _lib.FwdArgs(
+            M=M, K=K, N=N, r=r, bits=int(q.num_bits) if quantize else 32,
+            qtype=_lib.QTYPE_CODE_CPT.get(q.quantizer_type, 0), symmetric=1 if q.symmetric else 0,
+            quantize_input=1 if quantize else 0, x_per_channel=1 if (quantize and sx.numel() > 1) else 0, path=path,
+            x=x2.data_ptr(), sx=_lib.ptr(sx), zx=_lib.ptr(zx), x_limb_scale=_lib.ptr(limb_scale),
+            w_prep=self.w_eff.data_ptr() if f32 else self.w.data_ptr(), w_rowscale=None if f32 else self.rowscale.data_ptr(),
+            bias=_lib.ptr(bias), a_prep=self.aq_t.data_ptr() if r else None, b_prep=None, lora_scaling=0.0, y=y.data_ptr(),
+            workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
+            ev_gemm_begin=gemm_events[0] if gemm_events else None, ev_gemm_end=gemm_events[1] if gemm_events else None,
+            t_out=_lib.ptr(t), lora_on_fq_input=1)
         with torch.cuda.device(dev):
-            if path == _lib.PATH_F32:
-                w_ptr, rowscale = w_eff.data_ptr(), None
-            else:
-                if self.key != (N, K, dev):
-                    self.w = torch.empty(lib.spq_prep_f16x2_bytes(N, K, 0), dtype=torch.uint8, device=dev)
-                    self.rowscale = torch.empty((N + 127) // 128 * 128, dtype=torch.float32, device=dev)
-                    self.key, self.sig = (N, K, dev), None
-                one = _ones(dev)
-                fold = sx if path == _lib.PATH_F16X2 else one
-                full_sig = None if sig is None else (sig, path, q._epoch, q.num_bits)
-                if full_sig is None or full_sig != self.sig:
-                    rc = lib.spq_prepare_f16x2(w_eff.data_ptr(), N, K, one.data_ptr(), one.data_ptr(), 0, 32, 0, 1,
-                                               None, 0, None, None, 0, 0, 0, 1, 0.0, None, None, None, 0, 0, 0, 1,
-                                               fold.data_ptr(), 1 if fold.numel() > 1 else 0, self.w.data_ptr(),
-                                               self.w.numel(), self.rowscale.data_ptr(), None, st)
-                    _lib.check(rc, "spq_prepare_f16x2(cpt)")
-                    self.sig = full_sig
-                w_ptr, rowscale = self.w.data_ptr(), self.rowscale
-                if path == _lib.PATH_F16X3:
-                    limb_scale = _limb_scale(q)
-            args = _lib.FwdArgs(
-                M=M, K=K, N=N, r=r, bits=int(q.num_bits) if quantize else 32,
-                qtype=_lib.QTYPE_CODE_CPT.get(q.quantizer_type, 0), symmetric=1 if q.symmetric else 0,
-                quantize_input=1 if quantize else 0, x_per_channel=x_pc, path=path, x=x2.data_ptr(), sx=_lib.ptr(sx),
-                zx=_lib.ptr(zx), x_limb_scale=_lib.ptr(limb_scale), w_prep=w_ptr, w_rowscale=_lib.ptr(rowscale),
-                bias=_lib.ptr(bias), a_prep=_lib.ptr(down_p), b_prep=None, lora_scaling=0.0, y=y.data_ptr(),
-                workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
-                ev_gemm_begin=gemm_events[0] if gemm_events else None, ev_gemm_end=gemm_events[1] if gemm_events else None,
-                t_out=_lib.ptr(t), lora_on_fq_input=1)
             rc = lib.spq_linear_lora_fwd(ctypes.byref(args), st)
-            _lib.check(rc, "spq_linear_lora_fwd(cpt)")
-        return y if down is None else (y, t)
+        _lib.check(rc, "spq_linear_lora_fwd(cpt)")
+        return (y, t) if r else y
 
 
 def _sig(t):
@@ -397,22 +443,6 @@ class CPTLinear(nn.Module):
             self.quantizer_weight.set_num_bits(num_bits)
             self.quantizer_input.set_num_bits(num_bits)
 
-    # ---- weight side: FQ(W) + s FQ(B) FQ(A)^T, every quantizer in whatever state it is in (cpt_model.py:96-113)
-    def _lora_factors(self):
-        ql = self.lora_weight_quantizers[f'{self.current_bits}bit']
-        with torch.no_grad():
-            aq = ql(self.shared_lora.lora_A.detach())
-            bq = ql(self.shared_lora.lora_B.detach())
-        return ql, aq, bq
-
-    def _effective_weight(self, use_lora):
-        with torch.no_grad():
-            wq = self.quantizer_weight(self.linear.weight.detach())
-            if not use_lora:
-                return wq.contiguous(), None, None, None
-            ql, aq, bq = self._lora_factors()
-            return torch.addmm(wq, bq, aq.t(), alpha=float(self.shared_lora.scaling)), ql, aq, bq
-
     def _weights_sig(self, use_lora):
         lo = self.shared_lora
         sig = [_sig(self.linear.weight), self.current_bits, use_lora, self.quantizer_weight._epoch,
@@ -455,19 +485,19 @@ class CPTLinear(nn.Module):
             raise ValueError(f"Unknown quantizer type: {qi.quantizer_type}. Supported types: 'minmax', 'log'")
         x2 = x.detach().contiguous().float().view(-1, self.in_features)
         lead = tuple(x.shape[:-1])
-        sig = self._weights_sig(use_lora) if (self.cache_operands and not self.training) else None
-        reuse = sig is not None and self._gemm.sig is not None and self._gemm.sig[0] == sig and not want_t
-        if reuse:
-            w_eff, aq = self._w_eff_cached, None
-        else:
-            w_eff, ql, aq, bq = self._effective_weight(use_lora)
-            self._w_eff_cached = w_eff
         if x2.shape[0] == 0:
             return torch.empty(*lead, self.out_features, dtype=torch.float32, device=x.device)
-        down = aq.t().contiguous() if (want_t and use_lora) else None
-        out = self._gemm(x2, w_eff, self.linear.bias, qi, quantize, down=down, sig=sig, gemm_events=self._gemm_events)
-        self._last_path = self._gemm.path
-        if down is not None:
+        want_t = want_t and use_lora
+        path = _QuantGemm.path_for(qi, self.out_features, quantize)
+        if want_t and self.shared_lora.rank > 64:
+            path = _lib.PATH_F32
+        sig = self._weights_sig(use_lora) if (self.cache_operands and not self.training) else None
+        gm = self._gemm
+        if not (sig is not None and gm.sig == (sig, path, qi._epoch, qi.num_bits)) or want_t:
+            gm.prepare(self, use_lora, path, qi, quantize, want_aq_t=want_t, sig=sig)
+        out = gm.run(x2, self.linear.bias, qi, quantize, want_t=want_t, gemm_events=self._gemm_events)
+        self._last_path = gm.path
+        if want_t:
             y, t = out
             return y.view(*lead, self.out_features), t
         return out.view(*lead, self.out_features)
@@ -504,7 +534,10 @@ class _CPTLinearFunction(torch.autograd.Function):
             g2 = g.contiguous().float().reshape(-1, N)
             x2 = x.detach().contiguous().float().reshape(-1, K)
             s = float(lo.scaling)
-            w_eff, ql, aq, bq = module._effective_weight(use_lora)
+            gm = module._gemm
+            gm.prepare(module, use_lora, _lib.PATH_F32, qi, qi.active())     # W_eff, FQ(A), FQ(B) of this step (fp32)
+            w_eff, aq, bq = gm.w_eff, gm.aq, gm.bq
+            ql = module.lora_weight_quantizers[f'{module.current_bits}bit'] if use_lora else None
             gt = None
             want_gt = use_lora and need_A
             if need_x:

@@ -42,7 +42,8 @@ __device__ __forceinline__ float minmax_dequant(float q, float scale, float zp) 
 }
 
 // fp32 log2 / exp2 via fp64 (correctly rounded in all but ~1e-7 of cases); ATen's CPU log2f/powf are
-// <=1-ulp SLEEF kernels, so a last-bit difference is possible there, see DESIGN.md "log path".
+// <=1-ulp SLEEF kernels, so a last-bit difference is possible there, see DESIGN.md "log path".  Used for the calibration
+// statistics and for level decisions near a rounding tie (log_level).
 __device__ __forceinline__ float log2_rn(float v) { return (float)log2((double)v); }
 __device__ __forceinline__ float exp2_rn(float v) { return (float)exp2((double)v); }
 
@@ -70,17 +71,30 @@ __host__ __device__ inline LogParams make_log_params(int bits, bool sym, bool di
   return p;
 }
 
-// quantization_methods.py:45-61 -> integer level
+// quantization_methods.py:45-61 -> integer level, given log2|x|
 template <bool SYM>
-__device__ __forceinline__ float log_level(float x, float log_min, float log_range, const LogParams& p) {
+__device__ __forceinline__ float log_pre_round(float lg, float log_min, float log_range, const LogParams& p) {
   const float eps = 1e-5f;                                         // :35 (hard-coded)
-  float mag = fmaxf(fabsf(x), eps);                                // :45
-  float lg = log2_rn(mag);                                         // :47
   float ln = (lg - log_min) / fmaxf(log_range, eps);               // :49
   ln = clampf(ln, 0.f, 1.f);                                       // :50
-  float pre;
-  if (SYM) pre = ((ln - 0.5f) * 2.0f) * p.n2;                      // :54-55  centered * 2 * n_levels
-  else     pre = ln * p.n2;                                        // :60
+  if (SYM) return ((ln - 0.5f) * 2.0f) * p.n2;                     // :54-55  centered * 2 * n_levels
+  return ln * p.n2;                                                // :60
+}
+
+// The level is decided by a rounding, so log2 must be the correctly rounded one wherever the pre-round value sits near a
+// tie; everywhere else the hardware log2 (v_log_f32, <= 1 ulp) gives the same level.  Fast path + checked fallback: the
+// fp64 log2 runs for ~1e-4 of the elements instead of all of them (it was 70 % of the log fake-quant time).
+template <bool SYM>
+__device__ __forceinline__ float log_level(float x, float log_min, float log_range, const LogParams& p) {
+  const float eps = 1e-5f;
+  const float mag = fmaxf(fabsf(x), eps);                          // :45
+  const float lg_fast = __builtin_amdgcn_logf(mag);                // :47, approximately
+  float pre = log_pre_round<SYM>(lg_fast, log_min, log_range, p);
+  // |lg_fast - lg| <= 2 ulp, propagated through the slope of pre(lg), plus the roundings of the chain itself
+  const float slope = (SYM ? 2.0f : 1.0f) * p.n2 / fmaxf(log_range, eps);
+  const float err = 2.4e-7f * fmaxf(fabsf(lg_fast), 1.f) * slope + 1e-6f * fmaxf(fabsf(pre), 1.f);
+  const float tie_dist = 0.5f - fabsf(pre - rintf(pre));
+  if (!(tie_dist > err)) pre = log_pre_round<SYM>(log2_rn(mag), log_min, log_range, p);   // also catches NaN
   return clampf(rintf(pre), p.qlo, p.qhi);                         // :55-56 / :60-61
 }
 // :57,:64-74 -> dequantised value
@@ -94,7 +108,7 @@ __device__ __forceinline__ float log_dequant(float x, float q, float log_min, fl
   }
   else     qn = q / p.denom;                                       // :66
   float x_hat = qn * log_range + log_min;                          // :68 (unclamped range)
-  float mag = exp2_rn(x_hat);                                      // :70
+  float mag = __builtin_amdgcn_exp2f(x_hat);                       // :70  v_exp_f32 (<= 1 ulp, like ATen's pow); |x_hat| < 64 here
   float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);          // :43
   float out = mag * sgn;                                           // :72
   return (fabsf(x) < 1e-5f) ? 0.f : out;                           // :41,:74

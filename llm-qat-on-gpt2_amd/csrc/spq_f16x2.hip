@@ -1473,6 +1473,86 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_u8x2_kernel(GemmU8Args g
 
 #undef SPQ_PIECE
 // =================================================================================================
+// part2 CPTLinear (cpt_model.py:96-113): the LoRA branch consumes FQ(x) like the base term, so the layer is one contraction
+// against  W_eff = FQ(W) + s FQ(B) FQ(A)^T.  Two small kernels build it; the limb split is the ordinary row kernel.
+// =================================================================================================
+struct CptArgs {
+  const float* W; const float* sw; const float* zw;     // [N,K]; weight quantizer params ([N] or [1])
+  const float* A; const float* B;                       // [K,r], [N,r]
+  const float* sl; const float* zl;                     // the shared LoRA quantizer's params ([r] or [1])
+  float* aq; float* bq;                                 // out: FQ(A) [K,r], FQ(B) [N,r]
+  float* aqT;                                           // out, nullable: FQ(A)^T [ceil(r/64)*64, K], pad rows zero
+  float* w_eff;                                         // out: [N,K]
+  int N, K, r;
+  int w_pc, w_bits, w_qtype, w_sym;
+  int l_pc, l_bits, l_qtype, l_sym;
+  float scaling;
+};
+
+__global__ __launch_bounds__(256) void cpt_factors_kernel(CptArgs a) {
+  const int64_t na = (int64_t)a.K * a.r, nb = (int64_t)a.N * a.r;
+  const int rp = (a.r + 63) / 64 * 64;
+  const int64_t npad = a.aqT ? (int64_t)(rp - a.r) * a.K : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na + nb + npad; i += (int64_t)gridDim.x * 256) {
+    if (i < na) {
+      const int j = (int)(i % a.r);
+      const int64_t k = i / a.r;
+      const float v = fq_dispatch(a.A[i], a.sl[a.l_pc ? j : 0], a.zl[a.l_pc ? j : 0], a.l_bits, a.l_qtype, a.l_sym);
+      a.aq[i] = v;
+      if (a.aqT) a.aqT[(int64_t)j * a.K + k] = v;
+    } else if (i < na + nb) {
+      const int64_t e = i - na;
+      const int j = (int)(e % a.r);
+      a.bq[e] = fq_dispatch(a.B[e], a.sl[a.l_pc ? j : 0], a.zl[a.l_pc ? j : 0], a.l_bits, a.l_qtype, a.l_sym);
+    } else {
+      a.aqT[(int64_t)a.r * a.K + (i - na - nb)] = 0.f;
+    }
+  }
+}
+
+// 64 x 64 tile of W_eff per workgroup; thread (ty, tx) owns rows ty + 16 i, columns tx + 16 c (i, c < 4)
+constexpr int CPT_RMAX = 64;
+__global__ __launch_bounds__(256) void cpt_weff_kernel(CptArgs a) {
+  __shared__ float bs[64][CPT_RMAX + 1];
+  __shared__ float as_[64][CPT_RMAX + 1];
+  const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  for (int idx = tid; idx < 64 * a.r; idx += 256) {
+    const int row = idx / a.r, j = idx - row * a.r;
+    bs[row][j] = (n0 + row < a.N) ? a.bq[(int64_t)(n0 + row) * a.r + j] : 0.f;
+    as_[row][j] = (k0 + row < a.K) ? a.aq[(int64_t)(k0 + row) * a.r + j] : 0.f;
+  }
+  __syncthreads();
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[i][c] = 0.f;
+  for (int j = 0; j < a.r; ++j) {
+    float bv[4], av[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bv[i] = bs[ty + 16 * i][j]; av[i] = as_[tx + 16 * i][j]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[i][c] = fmaf(bv[i], av[c], acc[i][c]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 16 * i;
+    if (n >= a.N) continue;
+    const float swn = a.sw[a.w_pc ? n : 0], zwn = a.zw[a.w_pc ? n : 0];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = k0 + tx + 16 * c;
+      if (k >= a.K) continue;
+      const float wq = fq_dispatch(a.W[(int64_t)n * a.K + k], swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
+      a.w_eff[(int64_t)n * a.K + k] = wq + a.scaling * acc[i][c];     // out + lora * scaling, cpt_model.py:113
+    }
+  }
+}
+
+// =================================================================================================
 // host side
 // =================================================================================================
 struct PrepLayout { int64_t Np, Kp, Rp; size_t off_whi, off_wlo, off_bhi, off_blo, total; };
@@ -1662,3 +1742,38 @@ extern "C" int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const flo
   }
   return check_launch("spq_prepare_f16x2");
 }
+
+extern "C" int spq_prepare_cpt(const float* W, int64_t N, int64_t K, const float* sw, const float* zw, int w_per_channel,
+                               int w_bits, int w_qtype, int w_symmetric, const float* A, const float* B, int64_t r,
+                               const float* sl, const float* zl, int l_per_channel, int l_bits, int l_qtype,
+                               int l_symmetric, float scaling, const float* sx, int x_per_channel, int path,
+                               void* w_prep, size_t w_prep_bytes, float* w_rowscale, float* w_eff, float* aq, float* bq,
+                               float* aq_t, spq_stream_t stream) {
+  SPQ_REQUIRE(W && sw && zw && w_eff, "spq_prepare_cpt: null pointer");
+  SPQ_REQUIRE(N > 0 && K > 0 && r >= 0 && r <= CPT_RMAX, "spq_prepare_cpt: bad shape N=%lld K=%lld r=%lld (rank <= %d)",
+              (long long)N, (long long)K, (long long)r, CPT_RMAX);
+  SPQ_REQUIRE(r == 0 || (A && B && sl && zl && aq && bq), "spq_prepare_cpt: LoRA operands missing");
+  SPQ_REQUIRE(N < (1 << 30) && K < (1 << 30), "spq_prepare_cpt: dimension too large");
+  hipStream_t st = (hipStream_t)stream;
+  CptArgs c;
+  c.W = W; c.sw = sw; c.zw = zw; c.A = A; c.B = B; c.sl = sl; c.zl = zl; c.aq = aq; c.bq = bq; c.aqT = r > 0 ? aq_t : nullptr;
+  c.w_eff = w_eff; c.N = (int)N; c.K = (int)K; c.r = (int)r;
+  c.w_pc = w_per_channel; c.w_bits = w_bits; c.w_qtype = w_qtype; c.w_sym = w_symmetric;
+  c.l_pc = l_per_channel; c.l_bits = l_bits; c.l_qtype = l_qtype; c.l_sym = l_symmetric;
+  c.scaling = scaling;
+  if (r > 0) {
+    const int64_t total = (K + N) * r + (aq_t ? ((r + 63) / 64 * 64 - r) * K : 0);
+    cpt_factors_kernel<<<(unsigned)std::min<int64_t>((total + 255) / 256, 2048), 256, 0, st>>>(c);
+  }
+  dim3 grid((unsigned)((K + 63) / 64), (unsigned)((N + 63) / 64));
+  cpt_weff_kernel<<<grid, 256, 0, st>>>(c);
+  int rc = check_launch("spq_prepare_cpt");
+  if (rc || path == SPQ_PATH_F32) return rc;
+  SPQ_REQUIRE(path == SPQ_PATH_F16X2 || path == SPQ_PATH_F16X3, "spq_prepare_cpt: unknown operand path %d", path);
+  SPQ_REQUIRE(sx && w_prep && w_rowscale, "spq_prepare_cpt: limb buffers missing");
+  // the limb split of W_eff: identity weight quantizer (32 bit), input scale folded in for SPQ_PATH_F16X2
+  return spq_prepare_f16x2(w_eff, N, K, sx /* any valid scalar */, sx, 0, 32, SPQ_MINMAX, 1, nullptr, 0, nullptr, nullptr, 0, 0,
+                           0, 1, 0.f, nullptr, nullptr, nullptr, 0, 0, 0, 1, sx, x_per_channel, w_prep, w_prep_bytes,
+                           w_rowscale, nullptr, stream);
+}
+

@@ -1,0 +1,44 @@
+"""Forward (and forward+backward) time of part2's CPTLinear on the HIP path at the c_fc shape, next to part1's layer."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import llm_qat_on_gpt2_amd as pkg
+from oracle import ref_cpt as C          # workload generator only
+dev = 'cuda:0'
+PATHN = {1: 'f32', 2: 'f16x2', 3: 'u8x2', 4: 'f16x3'}
+
+
+def timeit(fn, n=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+for (M, K, N, r, bits, qt) in [(8192, 768, 3072, 16, 4, 'minmax'), (8192, 768, 3072, 16, 6, 'log'), (8192, 3072, 768, 16, 6, 'log'),
+                               (8192, 768, 3072, 16, 8, 'minmax')]:
+    W, bias, A, B, x0, x1 = C.make_cpt_workload(M, K, N, r, seed=0, batch=8)
+    m = pkg.CPTLinear(K, N, bit_widths=[bits, 32], quantizer_per_bit={bits: qt, 32: None}, shared_lora_rank=r, shared_lora_alpha=32)
+    with torch.no_grad():
+        m.linear.weight.copy_(W); m.linear.bias.copy_(bias); m.shared_lora.lora_A.copy_(A); m.shared_lora.lora_B.copy_(B)
+    m = m.to(dev).eval()
+    pkg.calibrate_cpt_layer(m, bits, [x0.to(dev), x1.to(dev)])
+    m.set_precision(bits)
+    x = x0.to(dev)
+    flop = 2 * M * (K * N + K * r + r * N)
+    with torch.no_grad():
+        t_eval = timeit(lambda: m(x))
+        m.cache_operands = False
+        t_requant = timeit(lambda: m(x))
+        m.cache_operands = True
+    m.train()
+    m.linear.weight.requires_grad_(False); m.linear.bias.requires_grad_(False)
+    xg = x.clone().requires_grad_(True)
+    g = torch.randn_like(m(xg)) * 1e-3
+
+    def step():
+        xg.grad = None
+        m(xg).backward(g)
+    t_train = timeit(step, 30)
+    print(f'CPT {qt}{bits} M={M} K={K} N={N} r={r} path={PATHN[m._last_path]}: eval {t_eval*1e3:.4f} ms ({flop/t_eval/1e12:.0f} TFLOP/s), '
+          f'weights re-quantized every call {t_requant*1e3:.4f} ms ({flop/t_requant/1e12:.0f} TFLOP/s), fwd+bwd {t_train*1e3:.3f} ms', flush=True)
