@@ -106,7 +106,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import llm_qat_on_gpt2_amd as pkg
-    from oracle import ref_cpu as O   # workload generator only (shared with the CPU leg); never on the timed path
+    from llm_qat_on_gpt2_amd import synthetic as O   # seeded input generator (the CPU leg's oracle draws the same tensors)
 
     W, bias, A, B, _, _ = O.make_workload(8, K_IN, N_OUT, RANK, seed=0)          # replicated weights
     gen = torch.Generator().manual_seed(1000 + 17 * rank)                        # this rank's batch shard

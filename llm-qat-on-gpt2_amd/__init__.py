@@ -9,7 +9,7 @@ from .fake_quantize import (LearnableFakeQuantize, LogQuantizationFunction, MinM
                             apply_log_quantization, apply_minmax_quantization, fake_quantize)
 from .sp_linear import LoRALayer, SPLinearWithLoRA
 from .calibration import SpqComm, allreduce_calibration_stats, calibrate_layer, calibrate_model
-from . import cpt
+from . import cpt, synthetic
 from .cpt import CPTLinear, LoRAAdapter, GradientQuantizer, calibrate_cpt_layer
 
 __all__ = ["SPLinearWithLoRA", "LoRALayer", "LearnableFakeQuantize", "MinMaxQuantizationFunction",

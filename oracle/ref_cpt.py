@@ -151,8 +151,4 @@ class OracleCPTLayer:
         return out + lora * self.scaling
 
 
-def make_cpt_workload(M, K, N, r, seed=0, batch=1):
-    """Synthetic CPTLinear tensors in the style of ref_cpu.make_workload; lora_B [N, r] non-zero (the reference's zero
-    init, cpt_model.py:24, would make the branch trivially zero)."""
-    W, bias, A, B_rn, x0, x1 = R.make_workload(M, K, N, r, seed=seed, batch=batch)
-    return W, bias, A, B_rn.t().contiguous(), x0, x1
+from llm_qat_on_gpt2_amd.synthetic import make_cpt_workload  # noqa: E402,F401  (shared input generator)

@@ -1,7 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import llm_qat_on_gpt2_amd as pkg
-from oracle import ref_cpu as O
+from llm_qat_on_gpt2_amd import synthetic as O          # seeded input generator
 dev = 'cuda:0'
 M, K, N, r, bits, qt = 8192, 768, 3072, 64, 4, 'minmax'
 W, bias, A, B, x0, x1 = O.make_workload(M, K, N, r, seed=0, batch=8)

@@ -5,7 +5,7 @@ Linear layers only (LN / attention / GELU are stock torch-ROCm and not on the pa
 import argparse, json, os, statistics, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import llm_qat_on_gpt2_amd as pkg
-from oracle import ref_cpu as O          # workload generator only
+from llm_qat_on_gpt2_amd import synthetic as O          # seeded input generator
 
 dev = 'cuda:0'
 PATHN = {1: 'f32', 2: 'f16x2', 3: 'u8x2', 4: 'f16x3'}

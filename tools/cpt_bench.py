@@ -2,7 +2,7 @@
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import llm_qat_on_gpt2_amd as pkg
-from oracle import ref_cpt as C          # workload generator only
+from llm_qat_on_gpt2_amd import synthetic as C          # seeded input generator
 dev = 'cuda:0'
 PATHN = {1: 'f32', 2: 'f16x2', 3: 'u8x2', 4: 'f16x3'}
 

@@ -2,7 +2,7 @@
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import llm_qat_on_gpt2_amd as pkg
-from oracle import ref_cpu as O          # workload generator only
+from llm_qat_on_gpt2_amd import synthetic as O          # seeded input generator
 dev = 'cuda:0'
 L = pkg._lib
 CASES = [  # M, K, N, r, bits, qtype, paths

@@ -3,7 +3,7 @@ every step, LoRA factors and the input receive gradients, the base weight is fro
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import llm_qat_on_gpt2_amd as pkg
-from oracle import ref_cpu as O          # workload generator only
+from llm_qat_on_gpt2_amd import synthetic as O          # seeded input generator
 dev = 'cuda:0'
 for (M, K, N, r, bits, qt) in [(8192, 768, 3072, 64, 4, 'minmax'), (8192, 3072, 768, 64, 4, 'minmax'), (8192, 1024, 4096, 64, 6, 'log')]:
     W, bias, A, B, x0, x1 = O.make_workload(M, K, N, r, seed=0, batch=8)
