@@ -54,6 +54,8 @@ enum spq_path {
                          products per algorithmic product; operands prepared with sx = 1 (no scale folding) */
 };
 
+enum spq_stage { SPQ_STAGE_ALL = 0, SPQ_STAGE_ACTIVATIONS = 1, SPQ_STAGE_CONTRACTION = 2 };
+
 typedef void* spq_stream_t;
 
 int spq_version(void);
@@ -190,6 +192,10 @@ typedef struct spq_fwd_args {
   /* 0: the LoRA branch consumes the raw x (part1 SPLinearWithLoRA, lora.py:149); 1: it consumes FQ(x) (part2 CPTLinear,
    * cpt_model.py:112) */
   int lora_on_fq_input;
+  /* enum spq_stage.  The F16 paths run two launches -- the activation pass (needs x, the input scale and a_prep) and the
+   * contraction (needs w_prep / b_prep).  Issuing them as two calls with the same arguments lets the caller prepare the
+   * weight operands on another stream while the activation pass runs, and make `stream` wait for them in between. */
+  int stage;
 } spq_fwd_args;
 
 size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path);
@@ -201,7 +207,8 @@ int spq_linear_lora_fwd(const spq_fwd_args* args, spq_stream_t stream);
  * lora.py:50, and folds the input scale sx[k] (quantization.py scale of quantizers_input) into the weight:
  *   W'[n,k] = FQ(W)[n,k] * sx[k],  B'[n,j] = scaling * FQ(B)[j,n];  both * 2^e[n], split into two fp16 limbs.
  * W [N,K]; B [r,N], A [K,r] (nullable when r = 0); B's quantizer params have N entries (per_channel) or 1, A's r or 1.
- * a_prep (out): FQ(A)^T in rows 0..r-1 of a caller-zeroed [ceil(r/64)*64, K] fp32 buffer (lora.py:49), same launch.
+ * a_prep (out): FQ(A)^T in rows 0..r-1 of a caller-zeroed [ceil(r/64)*64, K] fp32 buffer (lora.py:49), same launch;
+ * A may be NULL (with r > 0) when FQ(A)^T is produced separately (spq_fakequant_transposed).
  * w_prep: spq_prep_f16x2_bytes() bytes, 16-B aligned.  w_rowscale: ceil(N/128)*128 floats (2^-e[n]).
  * ------------------------------------------------------------------------------------------------- */
 size_t spq_prep_f16x2_bytes(int64_t N, int64_t K, int64_t r);

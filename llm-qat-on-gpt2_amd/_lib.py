@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspq.so")
 
 MINMAX, LOG = 0, 1
+STAGE_ALL, STAGE_ACTIVATIONS, STAGE_CONTRACTION = 0, 1, 2
 COMM_ID_BYTES = 128
 LIMB_SCALE_WORKSPACE_BYTES = 16384
 PATH_AUTO, PATH_F32, PATH_F16X2, PATH_U8X2, PATH_F16X3 = 0, 1, 2, 3, 4
@@ -37,7 +38,7 @@ class FwdArgs(C.Structure):
                 ("w_prep", _p), ("w_rowscale", _p), ("bias", _p), ("a_prep", _p), ("b_prep", _p),
                 ("lora_scaling", _f),
                 ("y", _p), ("workspace", _p), ("workspace_bytes", _sz),
-                ("ev_gemm_begin", _p), ("ev_gemm_end", _p), ("t_out", _p), ("lora_on_fq_input", _int)]
+                ("ev_gemm_begin", _p), ("ev_gemm_end", _p), ("t_out", _p), ("lora_on_fq_input", _int), ("stage", _int)]
 
 
 # name -> (restype, argtypes); must list every symbol include/spq.h declares (tests/test_cabi.py checks).

@@ -85,6 +85,7 @@ extern "C" int spq_linear_lora_fwd(const spq_fwd_args* a, spq_stream_t stream) {
     set_error("spq_linear_lora_fwd: unknown operand path %d", a->path);
     return SPQ_ERR_UNSUPPORTED;
   }
+  SPQ_REQUIRE(a->stage == SPQ_STAGE_ALL, "spq_linear_lora_fwd: stages are split for the F16 operand paths only");
   // ---- F32 path: [x -> FQ(x)] , [t = x . FQ(A)] , [y = FQ(x) . FQ(W)^T + bias + s * t . FQ(B)]
   char* ws = (char*)a->workspace;
   float* xq = (float*)ws;

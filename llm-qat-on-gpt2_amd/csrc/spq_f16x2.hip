@@ -1629,7 +1629,10 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   const unsigned xgrid = (unsigned)((a->M + XR - 1) / XR);
   const bool panel_ok = (a->K % 64 == 0) && L.Rp <= 64 && aligned16(a->x) && (a->r == 0 || aligned16(a->a_prep)) && aligned16(x.sx) &&
                         aligned16(x.zx);
-  if (panel_ok) {
+  const bool do_xpass = a->stage != SPQ_STAGE_CONTRACTION, do_gemm = a->stage != SPQ_STAGE_ACTIVATIONS;
+  if (!do_xpass) {
+    // the activation pass of this call ran earlier (same arguments, same workspace)
+  } else if (panel_ok) {
     static bool xattr = false;
     if (!xattr) {
       hipError_t e = hipFuncSetAttribute((const void*)xpass_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP_LDS);
@@ -1640,7 +1643,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   } else if (L.Rp <= 64) xpass_kernel<2><<<xgrid, 256, 0, st>>>(x);
   else xpass_kernel<4><<<xgrid, 256, 0, st>>>(x);
   int rc = check_launch("spq_linear_lora_fwd(xpass)");
-  if (rc) return rc;
+  if (rc || !do_gemm) return rc;
 
   if (a8) {
     GemmU8Args u;
@@ -1714,7 +1717,8 @@ extern "C" int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const flo
                                  float* w_rowscale, float* a_prep, spq_stream_t stream) {
   SPQ_REQUIRE(W && sw && zw && sx && w_prep && w_rowscale, "spq_prepare_f16x2: null pointer");
   SPQ_REQUIRE(N > 0 && K > 0 && r >= 0, "spq_prepare_f16x2: bad shape");
-  SPQ_REQUIRE(r == 0 || (B && sb && zb && A && sa && za && a_prep), "spq_prepare_f16x2: LoRA operands missing");
+  SPQ_REQUIRE(r == 0 || (B && sb && zb), "spq_prepare_f16x2: LoRA operands missing");
+  SPQ_REQUIRE(!A || (sa && za && a_prep), "spq_prepare_f16x2: LoRA-A quantizer parameters / output missing");
   SPQ_REQUIRE(w_bits >= 1 && b_bits >= 0 && a_bits >= 0, "spq_prepare_f16x2: bad bit-width");
   if (!f16x2_shape_ok(1, K, N, r)) { set_error("spq_prepare_f16x2: needs LoRA rank <= 128 and N %% 4 == 0 (got r=%lld N=%lld)", (long long)r, (long long)N); return SPQ_ERR_UNSUPPORTED; }
   const PrepLayout P = make_prep_layout(N, K, r);
@@ -1731,7 +1735,7 @@ extern "C" int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const flo
   a.x_pc = x_per_channel; a.scaling = scaling;
   a.A = A; a.sa = sa; a.za = za; a.aT = a_prep;
   a.a_pc = a_per_channel; a.a_bits = a_bits; a.a_qtype = a_qtype; a.a_sym = a_symmetric;
-  const int at_blocks = r > 0 ? (int)(((r + 31) / 32) * ((K + 31) / 32)) : 0;
+  const int at_blocks = (r > 0 && A) ? (int)(((r + 31) / 32) * ((K + 31) / 32)) : 0;   // A == NULL: FQ(A)^T is made elsewhere
   const bool wave_ok = (K % 4 == 0) && K <= 4 * 64 * PREP_MAXI && aligned16(W) && (!x_per_channel || aligned16(sx)) && r <= 128;
   if (wave_ok) {
     a.row_blocks = (int)(P.Np / 4);

@@ -8,6 +8,7 @@ layout, so the classes drop into ``models_sp.py`` unchanged.  ``forward`` enqueu
 """
 import ctypes
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -157,11 +158,11 @@ class _LimbGemm:
 
 class _Prepared:
     """Weight-side GEMM operands of one bit-width plus the signature of what they were built from."""
-    __slots__ = ("sig", "path", "w", "w_rowscale", "a", "b", "r", "x_limb_scale")
+    __slots__ = ("sig", "path", "w", "w_rowscale", "a", "b", "r", "x_limb_scale", "ready")
 
     def __init__(self):
         self.sig = None
-        self.w = self.w_rowscale = self.a = self.b = self.x_limb_scale = None
+        self.w = self.w_rowscale = self.a = self.b = self.x_limb_scale = self.ready = None
         self.r = 0
 
 
@@ -206,6 +207,8 @@ class SPLinearWithLoRA(nn.Module):
         self._prepared = {}
         self._gemm_events = None                  # (hipEvent_t, hipEvent_t) around the dominant kernel, for bench.py
         self.backward_limbs = True                # d/dx on the f16 MFMA limb kernel (False: fp32 MFMA kernel)
+        # weight-side limb split on a side stream, under the activation pass (opt-in: measured slower)
+        self.overlap_prepare = os.environ.get('SPQ_OVERLAP_PREPARE', '0') == '1'
         self._bwd_gemm = None
         self._last_t = None                       # LoRA-down product of the last training forward (consumed by autograd)
         self._last_path = None                    # operand path of the most recent fused forward
@@ -323,6 +326,13 @@ class SPLinearWithLoRA(nn.Module):
             ev_gemm_begin=self._gemm_events[0] if self._gemm_events else None,
             ev_gemm_end=self._gemm_events[1] if self._gemm_events else None, t_out=_lib.ptr(self._last_t))
         with torch.cuda.device(x.device):
+            if prep.ready is not None:                      # weight planes are being written on the side stream
+                a.stage = _lib.STAGE_ACTIVATIONS
+                rc = lib.spq_linear_lora_fwd(ctypes.byref(a), _lib.stream_ptr(x.device))
+                _lib.check(rc, "spq_linear_lora_fwd(activations)")
+                torch.cuda.current_stream(x.device).wait_event(prep.ready)
+                prep.ready = None
+                a.stage = _lib.STAGE_CONTRACTION
             rc = lib.spq_linear_lora_fwd(ctypes.byref(a), _lib.stream_ptr(x.device))
         _lib.check(rc, "spq_linear_lora_fwd")
         return y.view(*lead, N)
@@ -376,7 +386,9 @@ class SPLinearWithLoRA(nn.Module):
         if prep is not None and prep.sig == sig and self.cache_operands and not self.training:
             return prep
         prep = prep or _Prepared()
-        prep.path, prep.w_rowscale = path, None
+        prep.path = path
+        if path == _lib.PATH_F32:
+            prep.w_rowscale = None
         prep.r = lora.rank if use_lora else 0
         with torch.no_grad():
             if path == _lib.PATH_F32 or not use_lora:
@@ -398,7 +410,8 @@ class SPLinearWithLoRA(nn.Module):
         if getattr(prep, "w", None) is None or prep.w.dtype != torch.uint8 or prep.w.numel() < nbytes:
             prep.w = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
         n_pad = (N + 127) // 128 * 128
-        prep.w_rowscale = torch.empty(n_pad, dtype=torch.float32, device=W.device)
+        if prep.w_rowscale is None or prep.w_rowscale.numel() != n_pad or prep.w_rowscale.device != W.device:
+            prep.w_rowscale = torch.empty(n_pad, dtype=torch.float32, device=W.device)
         qb = lora.quantize_B if use_lora else None
         qa = lora.quantize_A if use_lora else None
         B = lora.lora_B.detach().contiguous() if use_lora else None
@@ -420,7 +433,23 @@ class SPLinearWithLoRA(nn.Module):
         else:
             sx_t = qx.scale
             prep.x_limb_scale = None
-        with torch.cuda.device(W.device):
+        # The limb planes of W and B are needed by the contraction only, FQ(A)^T already by the activation pass: with
+        # overlap on, FQ(A)^T is made on the current stream and the (much larger) W/B job on a side stream, so it runs
+        # under the activation pass of the forward that follows; that forward waits for `prep.ready` before its contraction.
+        overlap = self.overlap_prepare and use_lora
+        cur = torch.cuda.current_stream(W.device)
+        prep.ready = None
+        if overlap:
+            with torch.cuda.device(W.device):
+                rc = lib.spq_fakequant_transposed(
+                    A.data_ptr(), K, r, qa.scale.data_ptr(), qa.zero_point.data_ptr(), 1 if qa.scale.numel() > 1 else 0,
+                    int(qa.num_bits), _lib.QTYPE_CODE[qa.quantizer_type], 1 if qa.symmetric else 0, 1.0,
+                    prep.a.data_ptr(), cur.cuda_stream)
+            _lib.check(rc, "spq_fakequant_transposed")
+            side = _side_stream(W.device)
+            side.wait_stream(cur)                          # the previous forward's contraction may still read the planes
+            A = None
+        with torch.cuda.device(W.device), torch.cuda.stream(side if overlap else cur):
             rc = lib.spq_prepare_f16x2(
                 W.data_ptr(), N, K, qw.scale.data_ptr(), qw.zero_point.data_ptr(), 1 if qw.scale.numel() > 1 else 0,
                 int(qw.num_bits), _lib.QTYPE_CODE[qw.quantizer_type], 1 if qw.symmetric else 0,
@@ -434,8 +463,22 @@ class SPLinearWithLoRA(nn.Module):
                 sx_t.data_ptr(), 1 if sx_t.numel() > 1 else 0,
                 prep.w.data_ptr(), prep.w.numel(), prep.w_rowscale.data_ptr(), _lib.ptr(prep.a) if use_lora else None,
                 _lib.stream_ptr(W.device))
+            if overlap:
+                prep.ready = torch.cuda.Event()
+                prep.ready.record(side)
         _lib.check(rc, "spq_prepare_f16x2")
         prep.b = prep.w      # LoRA-B limbs live inside the same buffer
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 _ones_cache = {}
