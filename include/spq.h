@@ -54,6 +54,7 @@ enum spq_path {
                          products per algorithmic product; operands prepared with sx = 1 (no scale folding) */
 };
 
+enum spq_epilogue { SPQ_EPILOGUE_NONE = 0, SPQ_EPILOGUE_GELU = 1 };
 enum spq_stage { SPQ_STAGE_ALL = 0, SPQ_STAGE_ACTIVATIONS = 1, SPQ_STAGE_CONTRACTION = 2 };
 
 typedef void* spq_stream_t;
@@ -126,6 +127,15 @@ int spq_gemm_f32_tn(const float* P, int64_t ldp, const float* Q, int64_t ldq, in
                     float alpha, float* out, void* workspace, size_t workspace_bytes, spq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * SwitchableLayerNorm.forward (switchable_batchnorm.py:102-109), the producer of c_attn's and c_fc's input:
+ *   mean = x.mean(-1); var = x.var(-1, unbiased=False); out = weight * ((x - mean) / sqrt(var + eps)) + bias
+ * as one pass (the reference runs it as eight elementwise / reduction kernels).  x, out [rows, cols]; weight, bias [cols] of
+ * the active precision.  One wavefront per row, two-pass statistics on the row held in registers (cols <= 8192).
+ * ------------------------------------------------------------------------------------------------- */
+int spq_layernorm(const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias, float eps, float* out,
+                  spq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * The path's only exchange step: before finish_calibration every rank merges the running
  * statistics of its input quantizers (quantization.py:202-207 across ranks) with ONE in-place
  * all-reduce(MAX) over the flat fp32 buffer [-min_0 .. | max_0 ..] -- ncclAllReduce(ncclFloat, ncclMax) of
@@ -196,6 +206,9 @@ typedef struct spq_fwd_args {
    * contraction (needs w_prep / b_prep).  Issuing them as two calls with the same arguments lets the caller prepare the
    * weight operands on another stream while the activation pass runs, and make `stream` wait for them in between. */
   int stage;
+  /* enum spq_epilogue: SPQ_EPILOGUE_GELU stores gelu(y) (exact erf form, nn.GELU() of models_sp.py:107) instead of y --
+   * the activation between mlp.c_fc and mlp.c_proj fused into c_fc's store (F16X2 / F16X3 paths). */
+  int epilogue;
 } spq_fwd_args;
 
 size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path);

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libspq.so")
 
 MINMAX, LOG = 0, 1
 STAGE_ALL, STAGE_ACTIVATIONS, STAGE_CONTRACTION = 0, 1, 2
+EPILOGUE_NONE, EPILOGUE_GELU = 0, 1
 COMM_ID_BYTES = 128
 LIMB_SCALE_WORKSPACE_BYTES = 16384
 PATH_AUTO, PATH_F32, PATH_F16X2, PATH_U8X2, PATH_F16X3 = 0, 1, 2, 3, 4
@@ -38,7 +39,7 @@ class FwdArgs(C.Structure):
                 ("w_prep", _p), ("w_rowscale", _p), ("bias", _p), ("a_prep", _p), ("b_prep", _p),
                 ("lora_scaling", _f),
                 ("y", _p), ("workspace", _p), ("workspace_bytes", _sz),
-                ("ev_gemm_begin", _p), ("ev_gemm_end", _p), ("t_out", _p), ("lora_on_fq_input", _int), ("stage", _int)]
+                ("ev_gemm_begin", _p), ("ev_gemm_end", _p), ("t_out", _p), ("lora_on_fq_input", _int), ("stage", _int), ("epilogue", _int)]
 
 
 # name -> (restype, argtypes); must list every symbol include/spq.h declares (tests/test_cabi.py checks).
@@ -52,6 +53,7 @@ SIGNATURES = {
     "spq_gemm_f32_tn": (_int, [_p, _i64, _p, _i64, _i64, _i64, _i64, _f, _p, _p, _sz, _p]),
     "spq_prepare_cpt": (_int, [_p, _i64, _i64, _p, _p, _int, _int, _int, _int, _p, _p, _i64, _p, _p, _int, _int, _int, _int, _f,
                                 _p, _int, _int, _p, _sz, _p, _p, _p, _p, _p, _p]),
+    "spq_layernorm": (_int, [_p, _i64, _i64, _p, _p, _f, _p, _p]),
     "spq_version": (_int, []),
     "spq_last_error": (C.c_char_p, []),
     "spq_device_arch": (_int, [C.c_char_p, _int]),

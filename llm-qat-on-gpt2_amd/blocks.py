@@ -1,0 +1,135 @@
+"""The producers and consumers either side of the quantized linears inside a transformer block:
+``SwitchableLayerNorm`` (the tensor c_attn / c_fc quantize) as one HIP pass, and ``SPMLP`` with the GELU between c_fc and
+c_proj applied inside c_fc's contraction store.  Drop-ins for the reference's classes of the same names
+(part1_switchable_precision/switchable_batchnorm.py:6-109, models_sp.py:76-128); the reference's own ``SPBlock`` /
+``SPAttention`` / ``SPModel`` assemble them unchanged (rebind the two names in models_sp).
+"""
+from typing import List, Union
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .sp_linear import SPLinearWithLoRA
+
+
+class _ParamView:
+    """``ln_layers[key].weight`` / ``.bias`` of the reference (switchable_batchnorm.py:36-89): ``.data`` and ``.requires_grad``
+    forwarded to the parameter of that precision."""
+
+    def __init__(self, param):
+        self._param = param
+
+    @property
+    def data(self):
+        return self._param.data
+
+    @data.setter
+    def data(self, value):
+        self._param.data = value
+
+    @property
+    def requires_grad(self):
+        return self._param.requires_grad
+
+    @requires_grad.setter
+    def requires_grad(self, value):
+        self._param.requires_grad = value
+
+
+class _LayerNormCompat:
+    def __init__(self, parent, key):
+        self.parent, self.key = parent, key
+
+    @property
+    def weight(self):
+        return _ParamView(self.parent.weights[self.key])
+
+    @property
+    def bias(self):
+        return _ParamView(self.parent.biases[self.key])
+
+
+class SwitchableLayerNorm(nn.Module):
+    """One weight/bias pair per precision over a shared normalisation (switchable_batchnorm.py:6-109)."""
+
+    def __init__(self, normalized_shape: Union[int, List[int], torch.Size], precision_levels: List[int] = [6, 8, 16, 32],
+                 eps: float = 1e-5):
+        super().__init__()
+        if isinstance(normalized_shape, int):
+            normalized_shape = (normalized_shape,)
+        self.normalized_shape = tuple(normalized_shape)
+        self.precision_levels = sorted(precision_levels)
+        self.eps = eps
+        self.weights = nn.ParameterDict()
+        self.biases = nn.ParameterDict()
+        for precision in self.precision_levels:
+            self.weights[str(precision)] = nn.Parameter(torch.ones(normalized_shape))
+            self.biases[str(precision)] = nn.Parameter(torch.zeros(normalized_shape))
+        self.current_precision = max(self.precision_levels)
+        self.ln_layers = {str(p): _LayerNormCompat(self, str(p)) for p in self.precision_levels}
+
+    def set_precision(self, precision: int) -> int:
+        if precision not in self.precision_levels:
+            raise ValueError(f"Precision {precision} not supported. Available: {self.precision_levels}")
+        self.current_precision = precision
+        return self.current_precision
+
+    def _composed(self, x, weight, bias):
+        """The reference's formula on stock torch ops (autograd-capable; also what a CPU tensor gets)."""
+        dims = [-(i + 1) for i in range(len(self.normalized_shape))]
+        mean = x.mean(dim=dims, keepdim=True)
+        var = x.var(dim=dims, keepdim=True, unbiased=False)
+        return weight * ((x - mean) / torch.sqrt(var + self.eps)) + bias
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        weight = self.weights[str(self.current_precision)]
+        bias = self.biases[str(self.current_precision)]
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or bias.requires_grad)
+        cols = self.normalized_shape[0]
+        fused = (x.is_cuda and not needs_grad and len(self.normalized_shape) == 1 and x.dtype == torch.float32
+                 and cols % 4 == 0 and cols <= 8192 and x.numel() > 0)
+        if not fused:
+            return self._composed(x, weight, bias)
+        _lib.check_device(x.device)
+        xc = x.contiguous()
+        out = torch.empty_like(xc)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().spq_layernorm(xc.data_ptr(), xc.numel() // cols, cols, weight.data_ptr(), bias.data_ptr(),
+                                           float(self.eps), out.data_ptr(), _lib.stream_ptr(x.device))
+        _lib.check(rc, "spq_layernorm")
+        return out
+
+
+class SPMLP(nn.Module):
+    """models_sp.py:76-128: c_fc -> GELU -> c_proj on the drop-in linears, the GELU fused into c_fc's store."""
+
+    def __init__(self, config, bit_widths=None):
+        super().__init__()
+        if bit_widths is None:
+            bit_widths = getattr(config, 'bit_widths', [6, 8, 16, 32])
+        self.bit_widths = bit_widths
+        try:
+            lora_rank_per_bit = config.lora_rank_per_bit
+            lora_alpha_per_bit = config.lora_alpha_per_bit
+        except AttributeError as e:
+            raise AttributeError(f"Config missing required switchable precision attributes: {e}\n"
+                                 "Required: lora_rank_per_bit, lora_alpha_per_bit")
+        quantizer_per_bit = getattr(config, 'quantizer_per_bit', None)
+        per_channel = getattr(config, 'per_channel_quantization', True)
+        common = dict(bit_widths=bit_widths, lora_rank_per_bit=lora_rank_per_bit, lora_alpha_per_bit=lora_alpha_per_bit,
+                      quantizer_per_bit=quantizer_per_bit, per_channel=per_channel)
+        self.c_fc = SPLinearWithLoRA(config.n_embd, 4 * config.n_embd, **common)
+        self.c_proj = SPLinearWithLoRA(4 * config.n_embd, config.n_embd, **common)
+        self.act = nn.GELU()
+
+    def set_precision(self, bits) -> int:
+        if bits not in self.bit_widths:
+            raise ValueError(f"Bit width {bits} not in configured widths {self.bit_widths}")
+        self.c_fc.set_precision(bits)
+        self.c_proj.set_precision(bits)
+        return bits
+
+    def forward(self, hidden_states):
+        hidden_states = self.c_fc(hidden_states, activation='gelu')      # c_fc + self.act in one store where possible
+        return self.c_proj(hidden_states)

@@ -86,6 +86,7 @@ extern "C" int spq_linear_lora_fwd(const spq_fwd_args* a, spq_stream_t stream) {
     return SPQ_ERR_UNSUPPORTED;
   }
   SPQ_REQUIRE(a->stage == SPQ_STAGE_ALL, "spq_linear_lora_fwd: stages are split for the F16 operand paths only");
+  SPQ_REQUIRE(a->epilogue == SPQ_EPILOGUE_NONE, "spq_linear_lora_fwd: the fused epilogue exists on the F16 operand paths only");
   // ---- F32 path: [x -> FQ(x)] , [t = x . FQ(A)] , [y = FQ(x) . FQ(W)^T + bias + s * t . FQ(B)]
   char* ws = (char*)a->workspace;
   float* xq = (float*)ws;

@@ -109,6 +109,9 @@ __device__ __forceinline__ float fq_dispatch(float v, float s, float z, int bits
   return sym ? fq_value<SPQ_LOG, true>(v, s, z, bits, direct) : fq_value<SPQ_LOG, false>(v, s, z, bits, direct);
 }
 
+// nn.GELU() (models_sp.py:107): x * 0.5 * (1 + erf(x / sqrt(2))), the operation order of ATen's CPU kernel
+__device__ __forceinline__ float gelu_erf(float x) { return (x * 0.5f) * (1.0f + erff(x * 0.70710678118654752440f)); }
+
 // v = hi + lo up to 2^-22 |v|: hi = RN_f16(v), lo = RN_f16(v - hi); the residual is exact in fp32 (hi carries 11 of
 // v's 24 significant bits).  All in fp32: gfx950 has no f64->f16 conversion (clang expands one to ~30 instructions).
 __device__ __forceinline__ void split2(float v, _Float16& hi, _Float16& lo) {
@@ -940,7 +943,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_kernel(GemmF16Args
 #define SPQ_SYNC() do { if (!(DIAG & 64)) __syncthreads(); } while (0)
 // AL = activation limbs: 1 integer levels (SPQ_PATH_F16X2); 2 two limbs of FQ(x) * 2^G (SPQ_PATH_F16X3), the base segment
 // then alternates [hi limb x (Whi, Wlo)] and [lo limb x Whi] stages.  Compile-time, so that the F16X2 code is untouched.
-template <int DIAG, int AL>
+// EPI = 1: y = gelu(acc * scale + bias), the exact (erf) GELU of models_sp.py:107 fused into the store.
+template <int DIAG, int AL, int EPI = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1135,6 +1139,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
               const int m = bm + wm * 64 + tm * 16 + r16;
               float4 o;
               o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
+              if (EPI == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
               float* dst = g.y + (int64_t)m * g.N + n;
               if (DIAG & 4) { if (v.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }
               else if (interior) *reinterpret_cast<float4*>(dst) = o;
@@ -1624,6 +1629,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 needs an input quantizer of at most 8 bits (got %d)", a->bits);
     return SPQ_ERR_UNSUPPORTED;
   }
+  if (a->path == SPQ_PATH_U8X2 && a->epilogue != SPQ_EPILOGUE_NONE) { set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 has no fused epilogue"); return SPQ_ERR_UNSUPPORTED; }
   const bool a8 = a->path == SPQ_PATH_U8X2;   // levels as bytes + 3-slot ring kernel (opt-in)
   x.a8 = a8 ? 1 : 0;
   const unsigned xgrid = (unsigned)((a->M + XR - 1) / XR);
@@ -1689,11 +1695,18 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     if (mfma16) {
       (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     }
   }
   if (x3 && !mfma16) { set_error("spq_linear_lora_fwd: SPQ_PATH_F16X3 needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
-  if (mfma16 && x3) gemm_f16x2_s16_kernel<0, 2><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS, st>>>(g);
-  else if (mfma16) gemm_f16x2_s16_kernel<0, 1><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS, st>>>(g);
+  const bool gelu = a->epilogue == SPQ_EPILOGUE_GELU;
+  if (gelu && !mfma16) { set_error("spq_linear_lora_fwd: the GELU epilogue needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
+  const unsigned grid = gemm_grid(g.tiles_m * g.tiles_n);
+  if (mfma16 && x3 && gelu) gemm_f16x2_s16_kernel<0, 2, 1><<<grid, GEMM_THREADS, GEMM_LDS, st>>>(g);
+  else if (mfma16 && x3) gemm_f16x2_s16_kernel<0, 2><<<grid, GEMM_THREADS, GEMM_LDS, st>>>(g);
+  else if (mfma16 && gelu) gemm_f16x2_s16_kernel<0, 1, 1><<<grid, GEMM_THREADS, GEMM_LDS, st>>>(g);
+  else if (mfma16) gemm_f16x2_s16_kernel<0, 1><<<grid, GEMM_THREADS, GEMM_LDS, st>>>(g);
   else gemm_f16x2_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS, st>>>(g);
   if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
   return check_launch("spq_linear_lora_fwd(gemm_f16x2)");

@@ -171,6 +171,53 @@ __global__ __launch_bounds__(1024) void stats_merge_kernel(const float* __restri
   }
 }
 
+// SwitchableLayerNorm.forward (switchable_batchnorm.py:102-109).  One wave per row; the row lives in registers (NV float4 per
+// lane), statistics are two-pass (mean, then mean of squared deviations) like the reference's x.mean / x.var(unbiased=False).
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t rows, int cols,
+                                                        const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                        float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * cols;
+  float* orow = out + row * cols;
+  float4 v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols) { v[i] = *reinterpret_cast<const float4*>(xr + c); sum += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)cols;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < cols) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float den = sqrtf(sq / (float)cols + eps);           // torch.sqrt(var + eps)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < cols) {
+      const float4 wv = *reinterpret_cast<const float4*>(w + c), bv = *reinterpret_cast<const float4*>(b + c);
+      float4 o;
+      o.x = wv.x * ((v[i].x - mean) / den) + bv.x; o.y = wv.y * ((v[i].y - mean) / den) + bv.y;
+      o.z = wv.z * ((v[i].z - mean) / den) + bv.z; o.w = wv.w * ((v[i].w - mean) / den) + bv.w;
+      *reinterpret_cast<float4*>(orow + c) = o;
+    }
+  }
+}
+
 // {2^G, 2^-G} with max|x| * 2^G in [2^13, 2^14): the scale of the two-fp16-limb operand of an un-quantised tensor
 // (the incoming gradient of the backward GEMM).  One block over the per-slab maxima of stats_flat_kernel<true>.
 __global__ __launch_bounds__(256) void limb_scale_kernel(const float* __restrict__ pmax, int S, float* __restrict__ out2) {
@@ -417,6 +464,25 @@ extern "C" int spq_minmax_stats(const float* x, int64_t outer, int64_t chan, int
   stats_merge_kernel<<<1, 1024, 0, st>>>(pmin, pmax, S, C, log_domain, eps, log_eps_fill, first_batch, min_io,
                                          max_io);
   return check_launch("spq_minmax_stats(merge)");
+}
+
+extern "C" int spq_layernorm(const float* x, int64_t rows, int64_t cols, const float* weight, const float* bias, float eps,
+                             float* out, spq_stream_t stream) {
+  SPQ_REQUIRE(x && weight && bias && out, "spq_layernorm: null pointer");
+  SPQ_REQUIRE(rows > 0 && cols > 0, "spq_layernorm: empty tensor");
+  if (cols % 4 != 0 || cols > 8192 || !aligned16(x) || !aligned16(out) || !aligned16(weight) || !aligned16(bias)) {
+    set_error("spq_layernorm: needs cols %% 4 == 0, cols <= 8192 and 16-byte aligned tensors (cols = %lld)", (long long)cols);
+    return SPQ_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)ceil_div64(rows, 4);
+  const int nv = (int)ceil_div64(cols, 256);
+  if (nv <= 2) layernorm_kernel<2><<<grid, 256, 0, st>>>(x, rows, (int)cols, weight, bias, eps, out);
+  else if (nv <= 4) layernorm_kernel<4><<<grid, 256, 0, st>>>(x, rows, (int)cols, weight, bias, eps, out);
+  else if (nv <= 8) layernorm_kernel<8><<<grid, 256, 0, st>>>(x, rows, (int)cols, weight, bias, eps, out);
+  else if (nv <= 16) layernorm_kernel<16><<<grid, 256, 0, st>>>(x, rows, (int)cols, weight, bias, eps, out);
+  else layernorm_kernel<32><<<grid, 256, 0, st>>>(x, rows, (int)cols, weight, bias, eps, out);
+  return check_launch("spq_layernorm");
 }
 
 extern "C" int spq_dynamic_limb_scale(const float* x, int64_t n, float* scale_out2, void* workspace,

@@ -211,6 +211,7 @@ class SPLinearWithLoRA(nn.Module):
         self.overlap_prepare = os.environ.get('SPQ_OVERLAP_PREPARE', '0') == '1'
         self._bwd_gemm = None
         self._last_t = None                       # LoRA-down product of the last training forward (consumed by autograd)
+        self._activation_fused = False
         self._last_path = None                    # operand path of the most recent fused forward
 
     # ---- precision switching (lora.py:105-125): attribute flips only ---------------------------------------
@@ -237,7 +238,19 @@ class SPLinearWithLoRA(nn.Module):
         self._prepared.clear()
 
     # ---- forward (lora.py:127-150) ---------------------------------------------------------------------------
-    def forward(self, x):
+    def forward(self, x, activation=None):
+        """``activation='gelu'`` (not in the reference's signature; used by this package's SPMLP): the exact-erf GELU that
+        follows mlp.c_fc (models_sp.py:124-126) is applied to the output -- inside the contraction's store when the fused
+        no-grad path runs, as a separate ``F.gelu`` otherwise."""
+        if activation not in (None, 'gelu'):
+            raise ValueError(f"unknown activation {activation!r}")
+        y = self._forward(x, activation)
+        if activation == 'gelu' and not self._activation_fused:
+            y = F.gelu(y)
+        return y
+
+    def _forward(self, x, activation=None):
+        self._activation_fused = False
         if self.current_bits >= 32:
             return F.linear(x, self.linear.weight, self.linear.bias)
         key = f'{self.current_bits}bit'
@@ -261,7 +274,7 @@ class SPLinearWithLoRA(nn.Module):
                                            self, key)
         if needs_grad or qw.collecting_stats or (lora.enabled and (lora.quantize_A.collecting_stats or lora.quantize_B.collecting_stats)):
             return self._forward_composed(x, qx, qw, lora)
-        return self._forward_fused(x, key, qx, qw, lora)
+        return self._forward_fused(x, key, qx, qw, lora, activation=activation)
 
     def _forward_composed(self, x, qx, qw, lora):
         """Autograd-capable composition: HIP fake-quant kernels with straight-through backward, GEMMs by
@@ -271,7 +284,7 @@ class SPLinearWithLoRA(nn.Module):
             return base
         return base + lora(x)
 
-    def _forward_fused(self, x, key, qx, qw, lora, keep_t=False):
+    def _forward_fused(self, x, key, qx, qw, lora, keep_t=False, activation=None):
         _lib.require_gpu(x, "SPLinearWithLoRA input")
         _lib.check_device(x.device)
         W = self.linear.weight
@@ -325,6 +338,9 @@ class SPLinearWithLoRA(nn.Module):
             y=y.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
             ev_gemm_begin=self._gemm_events[0] if self._gemm_events else None,
             ev_gemm_end=self._gemm_events[1] if self._gemm_events else None, t_out=_lib.ptr(self._last_t))
+        if activation == 'gelu' and prep.path in (_lib.PATH_F16X2, _lib.PATH_F16X3) and _MFMA16:
+            a.epilogue = _lib.EPILOGUE_GELU
+            self._activation_fused = True
         with torch.cuda.device(x.device):
             if prep.ready is not None:                      # weight planes are being written on the side stream
                 a.stage = _lib.STAGE_ACTIVATIONS
@@ -470,6 +486,7 @@ class SPLinearWithLoRA(nn.Module):
         prep.b = prep.w      # LoRA-B limbs live inside the same buffer
 
 
+_MFMA16 = os.environ.get('SPQ_MFMA16', '1')[:1] != '0'      # the library's kernel choice (spq_f16x2.hip)
 _side_streams = {}
 
 

@@ -299,3 +299,39 @@ def build_calibrated_layer(W, bias, A, B, calib_batches, bits: int, qtype: str, 
         layer.forward(xb, calibration_mode=True)
     qx.finish()
     return layer
+
+
+# --------------------------------------------------------------------------------------------------
+# f1: the producers either side of the linears inside a block
+# --------------------------------------------------------------------------------------------------
+def switchable_layernorm(x, weight, bias, eps: float = 1e-5):
+    """SwitchableLayerNorm.forward over the last axis (switchable_batchnorm.py:102-109)."""
+    mean = x.mean(dim=[-1], keepdim=True)                                      # :104
+    var = x.var(dim=[-1], keepdim=True, unbiased=False)                        # :105
+    x_normalized = (x - mean) / torch.sqrt(var + eps)                          # :106
+    return weight * x_normalized + bias                                        # :109
+
+
+def sp_mlp_forward(x, fc: "OracleLayer", proj: "OracleLayer", calibration_mode: bool = False):
+    """SPMLP.forward (models_sp.py:124-128): c_fc -> nn.GELU() (exact erf) -> c_proj."""
+    h = F.gelu(fc.forward(x, calibration_mode))
+    return proj.forward(h, calibration_mode), h
+
+
+def build_calibrated_mlp(fc_t, proj_t, calib_batches, bits: int, qtype: str, per_channel: bool, alpha: float, rank: int,
+                         eps: float = 1e-5):
+    """CalibrationManager protocol (train_sp.py:47-123) on an SPMLP: weights and LoRA factors on themselves, both input
+    quantizers through LoRA-free forwards of the whole MLP (c_proj sees gelu of c_fc's calibration-mode output)."""
+    layers = []
+    for (W, bias, A, B) in (fc_t, proj_t):
+        qw = QuantState(bits, qtype, 0, per_channel, True, eps).calibrate_on(W)
+        qA = QuantState(bits, qtype, 1, per_channel, True, eps).calibrate_on(A)
+        qB = QuantState(bits, qtype, 1, per_channel, True, eps).calibrate_on(B)
+        qx = QuantState(bits, qtype, -1, per_channel, True, eps)
+        layers.append(OracleLayer(W, bias, A, B, qx, qw, qA, qB, alpha / rank, bits))
+    fc, proj = layers
+    fc.qx.start(); proj.qx.start()
+    for xb in calib_batches:
+        sp_mlp_forward(xb, fc, proj, calibration_mode=True)
+    fc.qx.finish(); proj.qx.finish()
+    return fc, proj

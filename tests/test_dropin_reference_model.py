@@ -40,6 +40,9 @@ def _build(swap):
         # what editing models_sp.py:14 (`from part1_switchable_precision.lora import SPLinearWithLoRA`) to import this
         # build's class does: rebind the name the model code instantiates
         models.SPLinearWithLoRA = pkg.SPLinearWithLoRA
+        if swap == "blocks":        # the LayerNorm producer and the MLP with the fused GELU as well
+            models.SwitchableLayerNorm = pkg.SwitchableLayerNorm
+            models.SPMLP = pkg.SPMLP
     torch.manual_seed(0)
     return models.SPLMHeadModel(_config())
 
@@ -80,3 +83,25 @@ def test_reference_model_builds_on_the_dropin_layers():
             q.calibrated = True
     with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
         mine(ids)
+
+
+def test_reference_model_builds_on_the_dropin_block_pieces():
+    """The same with SwitchableLayerNorm and SPMLP swapped too: identical state dict, reference checkpoint loads, identical
+    32-bit logits (the teacher path is plain torch)."""
+    import llm_qat_on_gpt2_amd as pkg
+    ref = _build(swap=False)
+    mine = _build(swap="blocks")
+    assert sum(isinstance(m, pkg.SwitchableLayerNorm) for m in mine.modules()) == 2 * 2 + 1
+    assert sum(isinstance(m, pkg.SPMLP) for m in mine.modules()) == 2
+    sd_ref, sd_mine = ref.state_dict(), mine.state_dict()
+    assert list(sd_ref.keys()) == list(sd_mine.keys())
+    mine.load_state_dict(sd_ref, strict=True)
+    assert mine.set_precision(4) == 4
+    assert all(m.current_precision == 4 for m in mine.modules() if isinstance(m, pkg.SwitchableLayerNorm))
+    ref.set_precision(32); mine.set_precision(32); ref.eval(); mine.eval()
+    ids = torch.randint(0, 97, (2, 16))
+    with torch.no_grad():
+        a, b = ref(ids), mine(ids)
+    pick = lambda o: o["logits"] if isinstance(o, dict) else (o.logits if hasattr(o, "logits") else (o if torch.is_tensor(o) else o[0]))
+    assert torch.equal(pick(a), pick(b))
+

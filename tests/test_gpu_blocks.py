@@ -1,0 +1,103 @@
+"""GPU parity of the block-level pieces: SwitchableLayerNorm as one HIP pass and SPMLP with the GELU fused
+into c_fc's store, against the fixtures the reference produced (tests/golden/blk_*.npz)."""
+import types
+
+import pytest
+import torch
+
+from helpers import assert_close_y
+from test_blocks_cpu import load_blk
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import llm_qat_on_gpt2_amd as p
+    p._lib.load()
+    return p
+
+
+@pytest.mark.parametrize("name", ["ln_768", "ln_1024", "ln_64"])
+def test_layernorm_kernel(pkg, name):
+    """Summation order of mean / variance differs from ATen's CPU reduction: agreement to a few ulp of the row's scale."""
+    meta, t = load_blk(name)
+    ln = pkg.SwitchableLayerNorm(meta["C"], precision_levels=[4, 8, 32], eps=1e-5).to(DEV)
+    x = t["x"].to(DEV)
+    for p in (4, 8, 32):
+        with torch.no_grad():
+            ln.weights[str(p)].copy_(t[f"w_{p}"]); ln.biases[str(p)].copy_(t[f"b_{p}"])
+            ln.set_precision(p)
+            y = ln(x)
+        ref = t[f"y_{p}"]
+        d = (y.cpu().double() - ref.double()).abs()
+        assert bool((d <= 2e-6 * ref.double().abs() + 2e-6).all()), f"{name}[{p}]: max abs diff {float(d.max()):.2e}"
+        with torch.no_grad():
+            assert torch.equal(y, ln(x))
+    # autograd takes the composed formula and agrees with the kernel
+    xg = x.clone().requires_grad_(True)
+    yg = ln(xg)
+    assert yg.grad_fn is not None and torch.allclose(yg.detach(), y, rtol=1e-5, atol=1e-5)
+
+
+def build_mlp(pkg, meta, t):
+    bits, r = meta["bits"], meta["r"]
+    cfg = types.SimpleNamespace(n_embd=meta["E"], bit_widths=[bits, 32], lora_rank_per_bit={bits: r, 32: 0},
+                                lora_alpha_per_bit={bits: meta["alpha"], 32: 0}, quantizer_per_bit={bits: meta["qtype"], 32: None},
+                                per_channel_quantization=True)
+    m = pkg.SPMLP(cfg, bit_widths=[bits, 32])
+    key = f"{bits}bit"
+    with torch.no_grad():
+        for lin, s in ((m.c_fc, "f"), (m.c_proj, "p")):
+            lin.linear.weight.copy_(t[f"W{s}"]); lin.linear.bias.copy_(t[f"b{s}"])
+            lin.lora_adapters[key].lora_A.copy_(t[f"A{s}"]); lin.lora_adapters[key].lora_B.copy_(t[f"B{s}"])
+    m = m.to(DEV).eval()
+    pkg.calibrate_model(m, bits, [t["x0"].to(DEV), t["x1"].to(DEV)])
+    return m, key
+
+
+@pytest.mark.parametrize("name", ["mlp_mm4", "mlp_mm8", "mlp_log6"])
+def test_spmlp_with_fused_gelu(pkg, name):
+    meta, t = load_blk(name)
+    m, key = build_mlp(pkg, meta, t)
+    qt = meta["qtype"]
+    tol = 1e-5 if qt == "minmax" else 2e-5
+    for lin, tag in ((m.c_fc, "fc"), (m.c_proj, "proj")):          # chained calibration (c_proj sees gelu(c_fc)) as the reference's
+        got, ref = lin.quantizers_input[key].scale.cpu(), t[f"{tag}.qx.scale"]
+        if qt == "minmax" and tag == "fc":
+            assert torch.equal(got, ref)
+        elif qt == "minmax" or tag == "fc":                         # downstream of a GEMM (+ erf): close, not bit-equal
+            assert torch.allclose(got, ref, rtol=2e-5, atol=1e-7), (name, tag)
+        else:   # log range of gelu(c_fc): its lower end is log2 of the smallest |h| above eps, where an absolute error of
+                # 1e-8 in h is a relative error of 1e-3 -- ill-conditioned in the reference itself
+            assert torch.allclose(got, ref, rtol=1e-3, atol=1e-6), (name, tag)
+        with torch.no_grad():                                       # compare like for like downstream
+            lin.quantizers_input[key].scale = ref.to(DEV); lin.quantizers_input[key].zero_point = t[f"{tag}.qx.zero_point"].to(DEV)
+            lin.quantizers_input[key]._epoch += 1
+    x2 = t["x2"].to(DEV)
+    with torch.no_grad():
+        h = m.c_fc(x2, activation="gelu")
+        assert m.c_fc._activation_fused, "the GELU did not go into the contraction's store"
+        assert_close_y(h, t["h"], f"{name}.gelu(c_fc)", tol)
+        h_unfused = torch.nn.functional.gelu(m.c_fc(x2))
+        assert_close_y(h, h_unfused.cpu(), f"{name}.fused vs separate gelu", 1e-6)
+        y = m(x2)
+    # c_proj quantizes h: an element of h within rounding distance of a level boundary may land one level away from the
+    # reference's, which moves that output ROW by one quantisation step; everything else must meet the usual bound
+    yd, yr = y.cpu().double(), t["y"].double()
+    rms = float(yr.pow(2).mean().sqrt())
+    bad_rows = ((yd - yr).abs() > tol * yr.abs() + tol * rms).any(dim=-1)
+    assert float(bad_rows.float().mean()) <= 0.02, f"{name}: {int(bad_rows.sum())} of {bad_rows.numel()} rows off"
+    # and exactly: the product's own h through the oracle's c_proj
+    from oracle import ref_cpu as O
+    fc, proj = O.build_calibrated_mlp((t["Wf"], t["bf"], t["Af"], t["Bf"]), (t["Wp"], t["bp"], t["Ap"], t["Bp"]),
+                                      [t["x0"], t["x1"]], meta["bits"], qt, True, meta["alpha"], meta["r"])
+    proj.qx.scale, proj.qx.zero_point = t["proj.qx.scale"], t["proj.qx.zero_point"]
+    assert_close_y(y, proj.forward(h.cpu()), f"{name}.c_proj(h)", tol)
+    # training mode: separate gelu under autograd, same values
+    m.train()
+    xg = x2.clone().requires_grad_(True)
+    yg = m(xg)
+    assert yg.grad_fn is not None and not m.c_fc._activation_fused
+    assert_close_y(yg, y.cpu(), f"{name}.train vs eval", 2e-5)
