@@ -133,3 +133,73 @@ class SPMLP(nn.Module):
     def forward(self, hidden_states):
         hidden_states = self.c_fc(hidden_states, activation='gelu')      # c_fc + self.act in one store where possible
         return self.c_proj(hidden_states)
+
+
+class SPAttention(nn.Module):
+    """models_sp.py:18-74: fused QKV projection, causal softmax attention (stock torch-ROCm ops, not on the quantized
+    path), output projection -- on the drop-in linears."""
+
+    def __init__(self, config, bit_widths):
+        super().__init__()
+        self.n_head = config.n_head
+        self.n_embd = config.n_embd
+        self.head_dim = self.n_embd // self.n_head
+        self.bit_widths = bit_widths
+        common = dict(bit_widths=bit_widths, lora_rank_per_bit=config.lora_rank_per_bit,
+                      lora_alpha_per_bit=config.lora_alpha_per_bit, quantizer_per_bit=config.quantizer_per_bit,
+                      per_channel=getattr(config, 'per_channel_quantization', True))
+        self.c_attn = SPLinearWithLoRA(config.n_embd, 3 * config.n_embd, **common)
+        self.c_proj = SPLinearWithLoRA(config.n_embd, config.n_embd, **common)
+        self.register_buffer("bias", torch.tril(torch.ones(config.n_positions, config.n_positions)))
+        self.use_sdpa = True        # False: the reference's explicit q k^T / softmax / v formula (models_sp.py:66-71)
+
+    def set_precision(self, bits) -> int:
+        self.current_bit_width = bits
+        self.c_attn.set_precision(bits)
+        self.c_proj.set_precision(bits)
+        return self.current_bit_width
+
+    def forward(self, hidden_states, attention_mask=None):
+        B, T, C = hidden_states.shape
+        q, k, v = self.c_attn(hidden_states).split(self.n_embd, dim=2)
+        q = q.view(B, T, self.n_head, self.head_dim).transpose(1, 2)
+        k = k.view(B, T, self.n_head, self.head_dim).transpose(1, 2)
+        v = v.view(B, T, self.n_head, self.head_dim).transpose(1, 2)
+        if self.use_sdpa and q.is_cuda:
+            # same causal softmax attention through torch-ROCm's fused kernel (no B x H x T x T matrix in HBM): 0.86 ms vs
+            # 3.4 ms at 32 x 12 x 1024 x 64 fp32, |difference| 1.5e-6 against the explicit formula below
+            out = torch.nn.functional.scaled_dot_product_attention(q, k, v, is_causal=True)
+        else:
+            att = (q @ k.transpose(-2, -1)) / (self.head_dim ** 0.5)
+            att = att.masked_fill(self.bias[:T, :T].to(att.device) == 0, float('-inf'))
+            out = torch.softmax(att, dim=-1) @ v
+        out = out.transpose(1, 2).contiguous().view(B, T, C)
+        return self.c_proj(out)
+
+
+class SPBlock(nn.Module):
+    """models_sp.py:130-171: pre-LN transformer block on SwitchableLayerNorm, SPAttention and SPMLP."""
+
+    def __init__(self, config, bit_widths):
+        super().__init__()
+        self.ln_1 = SwitchableLayerNorm(config.n_embd, precision_levels=bit_widths, eps=config.layer_norm_epsilon)
+        self.attn = SPAttention(config, bit_widths)
+        self.ln_2 = SwitchableLayerNorm(config.n_embd, precision_levels=bit_widths, eps=config.layer_norm_epsilon)
+        self.mlp = SPMLP(config, bit_widths)
+
+    def set_precision(self, bits) -> int:
+        self.ln_1.set_precision(bits)
+        self.attn.set_precision(bits)
+        self.ln_2.set_precision(bits)
+        self.mlp.set_precision(bits)
+        return bits
+
+    def forward(self, hidden_states, attention_mask=None, use_checkpoint=False):
+        if use_checkpoint:
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(self._forward, hidden_states, attention_mask)
+        return self._forward(hidden_states, attention_mask)
+
+    def _forward(self, hidden_states, attention_mask=None):
+        hidden_states = hidden_states + self.attn(self.ln_1(hidden_states), attention_mask)
+        return hidden_states + self.mlp(self.ln_2(hidden_states))

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference")
 sys.dont_write_bytecode = True
 
-from part1_switchable_precision.models_sp import SPMLP  # noqa: E402  (the reference)
+from part1_switchable_precision.models_sp import SPMLP, SPBlock  # noqa: E402  (the reference)
 from part1_switchable_precision.switchable_batchnorm import SwitchableLayerNorm  # noqa: E402
 
 from oracle import ref_cpu as O  # noqa: E402
@@ -87,7 +87,53 @@ def mlp_case(name, bits, qtype, E=64, r=8, alpha=16, M=96, seed=0):
     print(f"  mlp {name}: ok")
 
 
+def block_case(name, bits, qtype, E=64, H=4, T=24, Bsz=3, r=8, alpha=16, seed=0):
+    """A whole reference SPBlock (models_sp.py:130-171) after the CalibrationManager protocol, random weights."""
+    cfg = types.SimpleNamespace(n_embd=E, n_head=H, n_positions=32, layer_norm_epsilon=1e-5, bit_widths=[bits, 32],
+                                lora_rank_per_bit={bits: r, 32: 0}, lora_alpha_per_bit={bits: alpha, 32: 0},
+                                quantizer_per_bit={bits: qtype, 32: None}, per_channel_quantization=True)
+    torch.manual_seed(seed)
+    blk = SPBlock(cfg, bit_widths=[bits, 32]).eval()
+    key = f"{bits}bit"
+    g = torch.Generator().manual_seed(seed + 1)
+    for p_ in blk.parameters():
+        p_.data = torch.randn(p_.shape, generator=g) * (0.02 if p_.dim() > 1 else 0.1) + (1.0 if ("weights" in "") else 0.0)
+    for ln in (blk.ln_1, blk.ln_2):
+        for k_ in ln.weights:
+            ln.weights[k_].data = torch.randn(E, generator=g) * 0.1 + 1.0
+    lins = [blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc, blk.mlp.c_proj]
+    for lin in lins:
+        lin.lora_adapters[key].lora_A.data = O.kaiming_uniform_a5(lin.in_features, r, g)
+        lin.lora_adapters[key].lora_B.data = torch.randn(r, lin.out_features, generator=g) * 0.01
+    xs = [torch.randn(Bsz, T, E, generator=g) * 1.5 for _ in range(3)]
+    blk.set_precision(bits)
+    for lin in lins:
+        qw = lin.quantizers_weight[key]
+        qw.start_calibration(); qw(lin.linear.weight.data); qw.finish_calibration()
+        lo = lin.lora_adapters[key]
+        lo.quantize_A.start_calibration(); lo.quantize_A(lo.lora_A); lo.quantize_A.finish_calibration()
+        lo.quantize_B.start_calibration(); lo.quantize_B(lo.lora_B); lo.quantize_B.finish_calibration()
+    for lin in lins:
+        lin.quantizers_input[key].start_calibration(); lin.calibration_mode = True
+    for xb in xs[:2]:
+        blk(xb)
+    for lin in lins:
+        lin.calibration_mode = False; lin.quantizers_input[key].finish_calibration()
+    out = {f"param.{n}": p_.data.clone() for n, p_ in blk.named_parameters()}
+    out.update({"x0": xs[0], "x1": xs[1], "x2": xs[2], "y": blk(xs[2])})
+    for i, lin in enumerate(lins):
+        out[f"qx{i}.scale"] = lin.quantizers_input[key].scale
+        out[f"qx{i}.zero_point"] = lin.quantizers_input[key].zero_point
+    blk.set_precision(32)
+    out["y32"] = blk(xs[2])
+    meta = {"name": name, "bits": bits, "qtype": qtype, "E": E, "H": H, "T": T, "r": r, "alpha": alpha, "n_positions": 32}
+    np.savez_compressed(os.path.join(HERE, f"blk_block_{name}.npz"), meta=json.dumps(meta), **{k: v.numpy() for k, v in out.items()})
+    print(f"  block {name}: ok  y rms {float(out['y'].pow(2).mean().sqrt()):.3f}")
+
+
 if __name__ == "__main__":
+    block_case("mm4", 4, "minmax")
+    block_case("mm8", 8, "minmax", seed=3)
     ln_case("768", (2, 40), 768, 0)
     ln_case("1024", (3, 7), 1024, 1)
     ln_case("64", (5,), 64, 2)

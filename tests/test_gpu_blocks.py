@@ -101,3 +101,49 @@ def test_spmlp_with_fused_gelu(pkg, name):
     yg = m(xg)
     assert yg.grad_fn is not None and not m.c_fc._activation_fused
     assert_close_y(yg, y.cpu(), f"{name}.train vs eval", 2e-5)
+
+
+@pytest.mark.parametrize("name", ["block_mm4", "block_mm8"])
+def test_spblock_against_reference_fixture(pkg, name):
+    """A whole pre-LN block (models_sp.py:130-171) on the drop-ins -- LayerNorm kernel, four fused linears, GELU in c_fc's store,
+    stock-torch attention -- against the reference block's output after the same calibration protocol."""
+    meta, t = load_blk(name)
+    bits, r = meta["bits"], meta["r"]
+    cfg = types.SimpleNamespace(n_embd=meta["E"], n_head=meta["H"], n_positions=meta["n_positions"], layer_norm_epsilon=1e-5,
+                                bit_widths=[bits, 32], lora_rank_per_bit={bits: r, 32: 0}, lora_alpha_per_bit={bits: meta["alpha"], 32: 0},
+                                quantizer_per_bit={bits: meta["qtype"], 32: None}, per_channel_quantization=True)
+    blk = pkg.SPBlock(cfg, bit_widths=[bits, 32])
+    names = [n for n, _ in blk.named_parameters()]
+    assert names == [k[len("param."):] for k in t if k.startswith("param.")], "parameter names / order differ from the reference block"
+    with torch.no_grad():
+        for n, p_ in blk.named_parameters():
+            p_.copy_(t[f"param.{n}"])
+    blk = blk.to(DEV).eval()
+    x0, x1, x2 = (t[k].to(DEV) for k in ("x0", "x1", "x2"))
+    blk.set_precision(32)
+    with torch.no_grad():
+        assert_close_y(blk(x2), t["y32"], f"{name}.y32", 1e-5)
+    pkg.calibrate_model(blk, bits, [x0, x1])
+    key = f"{bits}bit"
+    lins = [blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc, blk.mlp.c_proj]
+    for i, lin in enumerate(lins):
+        q = lin.quantizers_input[key]
+        assert torch.allclose(q.scale.cpu(), t[f"qx{i}.scale"], rtol=3e-5, atol=1e-7), (name, i)
+        with torch.no_grad():
+            q.scale = t[f"qx{i}.scale"].to(DEV); q.zero_point = t[f"qx{i}.zero_point"].to(DEV); q._epoch += 1
+    with torch.no_grad():
+        y = blk(x2)
+    assert blk.mlp.c_fc._activation_fused
+    # every linear re-quantizes an upstream result that differs from the CPU's in the last ulps: a level flip moves one token's
+    # row by a quantisation step (see DESIGN.md 3.8); all other rows meet the bound
+    yd, yr = y.cpu().double(), t["y"].double()
+    rms = float(yr.pow(2).mean().sqrt())
+    bad_rows = ((yd - yr).abs() > 2e-5 * yr.abs() + 2e-5 * rms).any(dim=-1)
+    assert float(bad_rows.float().mean()) <= 0.05, f"{name}: {int(bad_rows.sum())} of {bad_rows.numel()} token rows off"
+    assert float((yd - yr).abs().max()) < 0.05 * rms
+    # the reference's explicit attention formula instead of torch's fused kernel: same result to fp32 rounding
+    blk.attn.use_sdpa = False
+    with torch.no_grad():
+        y_explicit = blk(x2)
+    same = ((y_explicit - y).abs() <= 2e-5 * y.abs() + 2e-5 * rms).all(dim=-1)
+    assert float((~same).float().mean()) <= 0.05
