@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .fake_quantize import LearnableFakeQuantize as _Part1FakeQuantize
-from .fake_quantize import fake_quantize
+from .fake_quantize import _eps_constants, fake_quantize
 from .sp_linear import _LimbGemm, _gemm_nt, _gemm_tn, _ones, _limb_scale
 
 
@@ -135,7 +135,7 @@ class LearnableFakeQuantize(_Part1FakeQuantize):
                     rc = _lib.load().spq_finish_scale(
                         self.running_min.data_ptr(), self.running_max.data_ptr(), self.running_min.numel(),
                         int(self.num_bits), _lib.QTYPE_CODE_CPT[self.quantizer_type], 1 if self.symmetric else 0,
-                        float(torch.tensor(self.eps, dtype=torch.float32)), scale.data_ptr(), zp.data_ptr(),
+                        _eps_constants(self.eps)[0], scale.data_ptr(), zp.data_ptr(),
                         _lib.stream_ptr(dev))
                 _lib.check(rc, "spq_finish_scale")
                 self.scales[self.num_bits] = scale

@@ -14,7 +14,7 @@ namespace spq {
 // ABS=true reduces |x| (log domain: log2 is monotone, so min/max commute with it).
 // =================================================================================================
 constexpr int kStatsBlock = 256;
-constexpr int kMaxSlabs = 128;
+constexpr int kMaxSlabs = 256;
 
 template <bool ABS>
 __device__ __forceinline__ void acc_minmax(float v, float& lo, float& hi) {
@@ -130,45 +130,60 @@ __global__ __launch_bounds__(kStatsBlock) void stats_flat_kernel(const float* __
   }
 }
 
-// part[S][chan] -> running update.  Single block: the log domain needs "does ANY element exceed eps"
-// across all channels before it may touch the running statistics (quantization.py:179-197).
-__global__ __launch_bounds__(1024) void stats_merge_kernel(const float* __restrict__ pmin,
-                                                           const float* __restrict__ pmax, int64_t S,
-                                                           int64_t chan, int log_domain, float eps,
-                                                           float log_eps_fill, int first,
-                                                           float* __restrict__ min_io,
-                                                           float* __restrict__ max_io) {
-  __shared__ float s_any[1024 / 64];
-  __shared__ int s_flag;
-  float gmax = -INFINITY;
-  // pass 1 (log only): global max of |x|
-  if (log_domain) {
-    for (int64_t i = threadIdx.x; i < S * chan; i += blockDim.x) gmax = fmaxf(gmax, pmax[i]);
-    gmax = wave_max(gmax);
-    if ((threadIdx.x & 63) == 0) s_any[threadIdx.x >> 6] = gmax;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float g = s_any[0];
-      for (int t = 1; t < (int)(blockDim.x >> 6); ++t) g = fmaxf(g, s_any[t]);
-      s_flag = (g > eps) ? 1 : 0;                                    // non_zero_mask.any()  (:177-179)
-    }
-    __syncthreads();
+// "does ANY element exceed eps" of the log domain (quantization.py:177-179), over the partial maxima of all channels.
+__global__ __launch_bounds__(1024) void stats_any_kernel(const float* __restrict__ pmax, int64_t n, float eps, int* __restrict__ flag) {
+  float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+  int64_t i = threadIdx.x;
+  for (; i + 3 * 1024 < n; i += 4 * 1024) {            // four independent loads in flight per lane
+    m0 = fmaxf(m0, pmax[i]); m1 = fmaxf(m1, pmax[i + 1024]); m2 = fmaxf(m2, pmax[i + 2048]); m3 = fmaxf(m3, pmax[i + 3072]);
   }
-  const bool any = log_domain ? (s_flag != 0) : true;
-  for (int64_t c = threadIdx.x; c < chan; c += blockDim.x) {
-    if (!any) {
-      if (first) { min_io[c] = log_eps_fill; max_io[c] = log_eps_fill; }  // :194-197
-      continue;                                                           // later batch: untouched
-    }
-    float lo = INFINITY, hi = -INFINITY;
-    for (int64_t s = 0; s < S; ++s) { lo = fminf(lo, pmin[s * chan + c]); hi = fmaxf(hi, pmax[s * chan + c]); }
-    if (log_domain) {                                                     // :182-183
-      lo = log2_rn(fmaxf(lo, eps));
-      hi = log2_rn(fmaxf(hi, eps));
-    }
-    if (first) { min_io[c] = lo; max_io[c] = hi; }                        // :188-190 / :202-204
-    else { min_io[c] = fminf(min_io[c], lo); max_io[c] = fmaxf(max_io[c], hi); }  // :192-193 / :206-207
+  for (; i < n; i += 1024) m0 = fmaxf(m0, pmax[i]);
+  float g = wave_max(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
+  __shared__ float sm[16];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = g;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int t = 1; t < 16; ++t) g = fmaxf(g, sm[t]);
+    *flag = (g > eps) ? 1 : 0;
   }
+}
+
+// part[S][chan] -> running update.  64 consecutive channels per workgroup (coalesced rows of the partial matrix), the four
+// waves take every fourth slab, two independent accumulator pairs per lane, LDS combine.
+__global__ __launch_bounds__(256) void stats_merge_kernel(const float* __restrict__ pmin,
+                                                          const float* __restrict__ pmax, int64_t S,
+                                                          int64_t chan, int log_domain, const int* __restrict__ any_flag,
+                                                          float eps, float log_eps_fill, int first,
+                                                          float* __restrict__ min_io,
+                                                          float* __restrict__ max_io) {
+  __shared__ float s_lo[4][64], s_hi[4][64];
+  const int cl = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+  const bool any = log_domain ? (*any_flag != 0) : true;
+  float lo0 = INFINITY, hi0 = -INFINITY, lo1 = INFINITY, hi1 = -INFINITY;
+  if (any && c < chan) {
+    int64_t sl = w;
+    for (; sl + 4 < S; sl += 8) {
+      lo0 = fminf(lo0, pmin[sl * chan + c]); hi0 = fmaxf(hi0, pmax[sl * chan + c]);
+      lo1 = fminf(lo1, pmin[(sl + 4) * chan + c]); hi1 = fmaxf(hi1, pmax[(sl + 4) * chan + c]);
+    }
+    for (; sl < S; sl += 4) { lo0 = fminf(lo0, pmin[sl * chan + c]); hi0 = fmaxf(hi0, pmax[sl * chan + c]); }
+  }
+  s_lo[w][cl] = fminf(lo0, lo1); s_hi[w][cl] = fmaxf(hi0, hi1);
+  __syncthreads();
+  if (w != 0 || c >= chan) return;
+  float lo = fminf(fminf(s_lo[0][cl], s_lo[1][cl]), fminf(s_lo[2][cl], s_lo[3][cl]));
+  float hi = fmaxf(fmaxf(s_hi[0][cl], s_hi[1][cl]), fmaxf(s_hi[2][cl], s_hi[3][cl]));
+  if (!any) {
+    if (first) { min_io[c] = log_eps_fill; max_io[c] = log_eps_fill; }  // :194-197
+    return;                                                             // later batch: untouched
+  }
+  if (log_domain) {                                                     // :182-183
+    lo = log2_rn(fmaxf(lo, eps));
+    hi = log2_rn(fmaxf(hi, eps));
+  }
+  if (first) { min_io[c] = lo; max_io[c] = hi; }                        // :188-190 / :202-204
+  else { min_io[c] = fminf(min_io[c], lo); max_io[c] = fmaxf(max_io[c], hi); }  // :192-193 / :206-207
 }
 
 // SwitchableLayerNorm.forward (switchable_batchnorm.py:102-109).  One wave per row; the row lives in registers (NV float4 per
@@ -410,7 +425,7 @@ extern "C" int spq_minmax_stats(const float* x, int64_t outer, int64_t chan, int
 
   auto launch_cols = [&](const float* src, int64_t rows, int64_t cols, float* omin, float* omax, bool absmode) {
     // enough slabs to fill the chip, at least 16 rows each
-    int64_t slabs = std::min<int64_t>(kMaxSlabs, std::max<int64_t>(1, rows / 16));
+    int64_t slabs = std::min<int64_t>(kMaxSlabs / 2, std::max<int64_t>(1, rows / 16));
     int64_t rps = ceil_div64(rows, slabs);
     rps = ceil_div64(rps, 4) * 4;
     slabs = ceil_div64(rows, rps);
@@ -461,8 +476,11 @@ extern "C" int spq_minmax_stats(const float* x, int64_t outer, int64_t chan, int
   }
   int rc = check_launch("spq_minmax_stats(partials)");
   if (rc) return rc;
-  stats_merge_kernel<<<1, 1024, 0, st>>>(pmin, pmax, S, C, log_domain, eps, log_eps_fill, first_batch, min_io,
-                                         max_io);
+  // the flag word lives at the very end of the workspace (spq_stats_workspace_bytes reserves 64 spare bytes)
+  int* any_flag = reinterpret_cast<int*>((char*)workspace + (spq_stats_workspace_bytes(outer, chan, inner, per_channel) - 16) / 16 * 16);
+  if (log_domain) stats_any_kernel<<<1, 1024, 0, st>>>(pmax, S * C, eps, any_flag);
+  stats_merge_kernel<<<(unsigned)ceil_div64(C, 64), 256, 0, st>>>(pmin, pmax, S, C, log_domain, any_flag, eps, log_eps_fill,
+                                                                   first_batch, min_io, max_io);
   return check_launch("spq_minmax_stats(merge)");
 }
 

@@ -35,6 +35,18 @@ def _param_axis(x_shape, p_shape):
     return ax
 
 
+_eps_cache = {}
+
+
+def _eps_constants(eps):
+    """(fp32(eps), fp32 log2(fp32(eps))) as Python floats -- the values torch.tensor(eps) / torch.log2 give the reference."""
+    v = _eps_cache.get(eps)
+    if v is None:
+        e32 = torch.tensor(eps, dtype=torch.float32)
+        v = _eps_cache[eps] = (float(e32), float(torch.log2(e32)))
+    return v
+
+
 def fake_quantize(x, scale, zero_point, num_bits, qtype, symmetric, want_levels=False):
     """One launch of ``spq_fakequant``: returns the dequantised tensor (and int32 levels on request).
 
@@ -44,8 +56,10 @@ def fake_quantize(x, scale, zero_point, num_bits, qtype, symmetric, want_levels=
     _lib.require_gpu(x, "fake-quant input")
     _lib.check_device(x.device)
     x = x.contiguous()
-    scale = scale.to(device=x.device, dtype=torch.float32).contiguous()
-    zero_point = zero_point.to(device=x.device, dtype=torch.float32).contiguous()
+    if scale.device != x.device or scale.dtype != torch.float32 or not scale.is_contiguous():
+        scale = scale.to(device=x.device, dtype=torch.float32).contiguous()
+    if zero_point.device != x.device or zero_point.dtype != torch.float32 or not zero_point.is_contiguous():
+        zero_point = zero_point.to(device=x.device, dtype=torch.float32).contiguous()
     out_shape = torch.broadcast_shapes(x.shape, scale.shape)
     tail = tuple(out_shape[len(out_shape) - x.dim():])
     if tail != tuple(x.shape):                      # the scale expands a size-1 axis of x
@@ -176,13 +190,13 @@ class LearnableFakeQuantize(nn.Module):
             elif self.temp_min.numel() != (chan if ax is not None else 1):
                 raise RuntimeError("calibration batches disagree on the channel count")
             is_log = self.quantizer_type == 'log'
-            eps32 = torch.tensor(self.eps, dtype=torch.float32)
+            eps32, log2_eps = _eps_constants(self.eps)
             lib = _lib.load()
             need = lib.spq_stats_workspace_bytes(outer, chan, inner, 0 if ax is None else 1)
             ws = _lib.workspace(xc.device, need)
             with torch.cuda.device(xc.device):
                 rc = lib.spq_minmax_stats(xc.data_ptr(), outer, chan, inner, 0 if ax is None else 1,
-                                          1 if is_log else 0, float(eps32), float(torch.log2(eps32)),
+                                          1 if is_log else 0, eps32, log2_eps,
                                           1 if first else 0, self.temp_min.data_ptr(), self.temp_max.data_ptr(),
                                           ws.data_ptr(), ws.numel(), _lib.stream_ptr(xc.device))
             _lib.check(rc, "spq_minmax_stats")
@@ -202,7 +216,7 @@ class LearnableFakeQuantize(nn.Module):
                     rc = _lib.load().spq_finish_scale(
                         self.running_min.data_ptr(), self.running_max.data_ptr(), self.running_min.numel(),
                         int(self.num_bits), _lib.QTYPE_CODE[self.quantizer_type], 1 if self.symmetric else 0,
-                        float(torch.tensor(self.eps, dtype=torch.float32)), scale.data_ptr(), zp.data_ptr(),
+                        _eps_constants(self.eps)[0], scale.data_ptr(), zp.data_ptr(),
                         _lib.stream_ptr(dev))
                 _lib.check(rc, "spq_finish_scale")
                 self.scale = scale
