@@ -209,6 +209,10 @@ typedef struct spq_fwd_args {
   /* enum spq_epilogue: SPQ_EPILOGUE_GELU stores gelu(y) (exact erf form, nn.GELU() of models_sp.py:107) instead of y --
    * the activation between mlp.c_fc and mlp.c_proj fused into c_fc's store (F16X2 / F16X3 paths). */
   int epilogue;
+  /* optional device {2^S, 2^-S} with (bound of |a_prep|) * 2^S in [2^13, 2^14): the LoRA-down product of the activation
+   * pass then runs on the f16 matrix pipe (two fp16 limbs of x * 2^g[m] per 32-row panel and of a_prep * 2^S) instead of
+   * the fp32-input MFMA.  NULL: fp32-input MFMA. */
+  const float* a_limb_scale;
 } spq_fwd_args;
 
 size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path);

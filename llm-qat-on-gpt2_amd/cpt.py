@@ -362,6 +362,7 @@ class _QuantGemm:
                                                self.w.numel(), self.rowscale.data_ptr(), None, st)
                     _lib.check(rc, "spq_prepare_f16x2(cpt)")
         self.path, self.r = path, r
+        self.a_limb_scale = _limb_scale(ql) if (want_aq_t and r and ql is not None and ql.active()) else None
         self.sig = None if sig is None else (sig, path, qi._epoch, qi.num_bits)
 
     def run(self, x2, bias, q, quantize, want_t=False, gemm_events=None):
@@ -392,7 +393,7 @@ class _QuantGemm:
             bias=_lib.ptr(bias), a_prep=self.aq_t.data_ptr() if r else None, b_prep=None, lora_scaling=0.0, y=y.data_ptr(),
             workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
             ev_gemm_begin=gemm_events[0] if gemm_events else None, ev_gemm_end=gemm_events[1] if gemm_events else None,
-            t_out=_lib.ptr(t), lora_on_fq_input=1)
+            t_out=_lib.ptr(t), lora_on_fq_input=1, a_limb_scale=_lib.ptr(self.a_limb_scale) if r else None)
         with torch.cuda.device(dev):
             rc = lib.spq_linear_lora_fwd(ctypes.byref(args), st)
         _lib.check(rc, "spq_linear_lora_fwd(cpt)")
@@ -546,7 +547,8 @@ class _CPTLinearFunction(torch.autograd.Function):
                     if module._bwd_gemm is None:
                         module._bwd_gemm = _LimbGemm()
                     if want_gt and bq.shape[1] <= 128:
-                        gx, gt = module._bwd_gemm(g2, w_t, down=bq.t().contiguous())   # g . FQ(B) rides the activation pass
+                        gx, gt = module._bwd_gemm(g2, w_t, down=bq.t().contiguous(),
+                                                  down_scale=_limb_scale(ql) if ql.active() else None)   # g . FQ(B) rides the activation pass
                     else:
                         gx = module._bwd_gemm(g2, w_t)
                 else:

@@ -114,7 +114,7 @@ class _LimbGemm:
             self.xscale = torch.empty(2, dtype=torch.float32, device=device)
             self.key = (R, C, device)
 
-    def __call__(self, a: torch.Tensor, b: torch.Tensor, down: torch.Tensor = None):
+    def __call__(self, a: torch.Tensor, b: torch.Tensor, down: torch.Tensor = None, down_scale: torch.Tensor = None):
         """``down`` [r, C] (optional, r <= 128): also returns a . down^T [M, r], computed inside the activation pass."""
         M, C = a.shape
         R = b.shape[0]
@@ -150,7 +150,8 @@ class _LimbGemm:
                 path=_lib.PATH_F16X3, x=a.data_ptr(), sx=None, zx=None, x_limb_scale=self.xscale.data_ptr(),
                 w_prep=self.w.data_ptr(), w_rowscale=self.rowscale.data_ptr(), bias=None, a_prep=_lib.ptr(down_p),
                 b_prep=None, lora_scaling=0.0, y=out.data_ptr(), workspace=ws.data_ptr(),
-                workspace_bytes=ws.numel() - sws - 256, ev_gemm_begin=None, ev_gemm_end=None, t_out=_lib.ptr(t))
+                workspace_bytes=ws.numel() - sws - 256, ev_gemm_begin=None, ev_gemm_end=None, t_out=_lib.ptr(t),
+                a_limb_scale=_lib.ptr(down_scale) if (down is not None and _LORA_DOWN_F16) else None)
             rc = lib.spq_linear_lora_fwd(ctypes.byref(args), st)
             _lib.check(rc, "spq_linear_lora_fwd(backward)")
         return out if down is None else (out, t)
@@ -158,11 +159,11 @@ class _LimbGemm:
 
 class _Prepared:
     """Weight-side GEMM operands of one bit-width plus the signature of what they were built from."""
-    __slots__ = ("sig", "path", "w", "w_rowscale", "a", "b", "r", "x_limb_scale", "ready")
+    __slots__ = ("sig", "path", "w", "w_rowscale", "a", "b", "r", "x_limb_scale", "ready", "a_limb_scale")
 
     def __init__(self):
         self.sig = None
-        self.w = self.w_rowscale = self.a = self.b = self.x_limb_scale = self.ready = None
+        self.w = self.w_rowscale = self.a = self.b = self.x_limb_scale = self.ready = self.a_limb_scale = None
         self.r = 0
 
 
@@ -337,7 +338,8 @@ class SPLinearWithLoRA(nn.Module):
             b_prep=_lib.ptr(prep.b) if r else None, lora_scaling=float(lora.scaling) if r else 0.0,
             y=y.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
             ev_gemm_begin=self._gemm_events[0] if self._gemm_events else None,
-            ev_gemm_end=self._gemm_events[1] if self._gemm_events else None, t_out=_lib.ptr(self._last_t))
+            ev_gemm_end=self._gemm_events[1] if self._gemm_events else None, t_out=_lib.ptr(self._last_t),
+            a_limb_scale=_lib.ptr(prep.a_limb_scale) if r else None)
         if activation == 'gelu' and prep.path in (_lib.PATH_F16X2, _lib.PATH_F16X3) and _MFMA16:
             a.epilogue = _lib.EPILOGUE_GELU
             self._activation_fused = True
@@ -449,6 +451,8 @@ class SPLinearWithLoRA(nn.Module):
         else:
             sx_t = qx.scale
             prep.x_limb_scale = None
+        # LoRA-down product of the activation pass on the f16 matrix pipe: FQ(A)^T is split into limbs of FQ(A) * 2^S there
+        prep.a_limb_scale = _limb_scale(qa) if (use_lora and _LORA_DOWN_F16 and qa.num_bits < 32) else None
         # The limb planes of W and B are needed by the contraction only, FQ(A)^T already by the activation pass: with
         # overlap on, FQ(A)^T is made on the current stream and the (much larger) W/B job on a side stream, so it runs
         # under the activation pass of the forward that follows; that forward waits for `prep.ready` before its contraction.
@@ -487,6 +491,8 @@ class SPLinearWithLoRA(nn.Module):
 
 
 _MFMA16 = os.environ.get('SPQ_MFMA16', '1')[:1] != '0'      # the library's kernel choice (spq_f16x2.hip)
+# x . FQ(A) of the activation pass as fp16 limbs on the f16 matrix pipe (xpass_panel16_kernel); SPQ_LORA_DOWN_F16=0: fp32-input MFMA
+_LORA_DOWN_F16 = os.environ.get('SPQ_LORA_DOWN_F16', '1') != '0'
 _side_streams = {}
 
 
@@ -511,6 +517,16 @@ def _ones(device):
 def _limb_scale(q: LearnableFakeQuantize) -> torch.Tensor:
     """Device tensor {2^G, 2^-G} with bound(|FQ(x)|) * 2^G in [2^13, 2^14), from the quantizer's own range:
     minmax symmetric n*scale; asymmetric max(|0-zp|, |2^b-1-zp|)*scale; log 2^(log_min + log_range).  No host sync."""
+    key = (q._epoch, int(q.num_bits), q.scale.data_ptr(), q.scale._version)
+    cached = getattr(q, "_limb_scale_cache", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    out = _limb_scale_uncached(q)
+    q._limb_scale_cache = (key, out)           # a dozen tiny launches: keep it per calibration epoch
+    return out
+
+
+def _limb_scale_uncached(q) -> torch.Tensor:
     s, z = q.scale.detach().float(), q.zero_point.detach().float()
     if q.quantizer_type == 'log':
         bound = torch.exp2((z + s.clamp(min=0)).amax())
@@ -520,9 +536,12 @@ def _limb_scale(q: LearnableFakeQuantize) -> torch.Tensor:
         bound = (torch.maximum(z.abs(), (float(2 ** q.num_bits - 1) - z).abs()) * s).amax()
     bound = bound * (1.0 + 2.0 ** -10)                                  # rounding margin
     _, e = torch.frexp(bound)                                           # bound = m * 2^e, m in [0.5, 1)
-    p = torch.ldexp(torch.ones_like(bound), 14 - e)
-    p = torch.where(torch.isfinite(p) & (bound > 0), p, torch.ones_like(p))
-    return torch.stack([p, 1.0 / p]).to(torch.float32).contiguous()
+    # exact powers of two, built from the exponent field (torch.ldexp goes through a float pow: 2^16 came out as 65535.996)
+    k = torch.clamp(14 - e.to(torch.int32), -100, 100)
+    k = torch.where(torch.isfinite(bound) & (bound > 0), k, torch.zeros_like(k))
+    p = ((k + 127) << 23).view(torch.float32)
+    pinv = ((127 - k) << 23).view(torch.float32)
+    return torch.stack([p.reshape(()), pinv.reshape(())]).contiguous()
 
 
 class _SPLinearFunction(torch.autograd.Function):
@@ -588,7 +607,8 @@ class _SPLinearFunction(torch.autograd.Function):
                 if module._bwd_gemm is None:
                     module._bwd_gemm = _LimbGemm()
                 if ctx.use_lora and gt is None:
-                    gx, gt = module._bwd_gemm(g2, w_t, down=bq)                  # g . FQ(B)^T rides the activation pass
+                    gx, gt = module._bwd_gemm(g2, w_t, down=bq, down_scale=_limb_scale(lora.quantize_B)
+                                              if lora.quantize_B.num_bits < 32 else None)   # g . FQ(B)^T rides the activation pass
                 else:
                     gx = module._bwd_gemm(g2, w_t)
                 if log_x:

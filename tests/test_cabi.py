@@ -54,5 +54,5 @@ def test_argument_validation_without_gpu(lib):
 
 def test_struct_layout_matches_header():
     import llm_qat_on_gpt2_amd as pkg
-    # 4 int64 + 6 int + 4 ptr + 5 ptr + float(+pad) + 2 ptr + size_t + 2 ptr + t_out + 3 int(+pad)
-    assert ctypes.sizeof(pkg._lib.FwdArgs) == 4 * 8 + 6 * 4 + 9 * 8 + 8 + 3 * 8 + 2 * 8 + 8 + 16
+    # 4 int64 + 6 int + 4 ptr + 5 ptr + float(+pad) + 2 ptr + size_t + 2 ptr + t_out + 3 int(+pad) + a_limb_scale
+    assert ctypes.sizeof(pkg._lib.FwdArgs) == 4 * 8 + 6 * 4 + 9 * 8 + 8 + 3 * 8 + 2 * 8 + 8 + 16 + 8
