@@ -575,18 +575,24 @@ __global__ __launch_bounds__(256) void xpass_kernel(XPassArgs a) {
 // through a double buffer one chunk ahead.  LDS images are [chunk][row][64 floats]; the 16-B position p of row r holds
 // source chunk p ^ (r & 15), so the MFMA operand reads (ds_read_b128, row = lane & 31) are conflict-free.
 // -------------------------------------------------------------------------------------------------------------------
-constexpr int XP_CHUNKS = 12;                              // panel = 12 chunks x 64 columns
-constexpr int XP_XS = XP_CHUNKS * XR * 64 * 4;             // 96 KB
+constexpr int XP_CHUNKS = 12;                              // panel = 12 chunks x 64 columns (one workgroup per CU)
+constexpr int XP_CHUNKS_SMALL = 4;                         // 66 KB of LDS: two workgroups per CU, for M large enough to have them
 constexpr int XP_AS = 64 * 64 * 4;                         // 16 KB per FQ(A)^T chunk (64 rows of r)
-constexpr int XP_SX = 2 * XP_CHUNKS * 64 * 4;              // 6 KB: the panel's input scales and zero points
 constexpr int XP_NAS = 2;                                  // FQ(A)^T chunk buffers
-constexpr int XP_LDS = XP_XS + XP_NAS * XP_AS + XP_SX;     // 131 KB
+constexpr int xp_xs(int ch) { return ch * XR * 64 * 4; }   // x panel image: 96 KB / 32 KB
+constexpr int xp_sx(int ch) { return 2 * ch * 64 * 4; }    // the panel's input scales and zero points
+constexpr int xp_lds(int ch) { return xp_xs(ch) + XP_NAS * XP_AS + xp_sx(ch); }   // 131 KB / 66 KB
+constexpr int XP_XS = xp_xs(XP_CHUNKS);
+constexpr int XP_LDS = xp_lds(XP_CHUNKS);
 
+// CH = chunks per panel: 12 (whole 768-column rows in flight, one workgroup per CU) while there is at most one 32-row block
+// per CU, 4 (two resident workgroups that cover each other's load phases: 276 -> 223 us at 32768 x 3072) beyond that.
+template <int CH>
 __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) char xsm[];
   char* xs = xsm;
-  char* as = xsm + XP_XS;
-  float* sxs = reinterpret_cast<float*>(xsm + XP_XS + XP_NAS * XP_AS);
+  char* as = xsm + xp_xs(CH);
+  float* sxs = reinterpret_cast<float*>(xsm + xp_xs(CH) + XP_NAS * XP_AS);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // 8 waves: two per SIMD, so one's VALU runs under the other's MFMAs
   const int m0 = blockIdx.x * XR;
@@ -635,12 +641,12 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
 
   int gc = 0;
   if (with_lora) SPQ_LOAD_A(0);
-  for (int p0 = 0; p0 < a.K; p0 += XP_CHUNKS * 64) {
-    const int nch = min(XP_CHUNKS, (a.K - p0) / 64);
+  for (int p0 = 0; p0 < a.K; p0 += CH * 64) {
+    const int nch = min(CH, (a.K - p0) / 64);
     for (int c = 0; c < nch; ++c) glds16(x_src + p0 + c * 64, xs + c * (XR * 256) + w * 1024);
     for (int k = tid; k < nch * 64; k += 512) {
       sxs[k] = a.x_pc ? a.sx[p0 + k] : a.sx[0];
-      sxs[XP_CHUNKS * 64 + k] = (a.limbs || a.lora_fq) ? (a.x_pc ? a.zx[p0 + k] : a.zx[0]) : 0.f;
+      sxs[CH * 64 + k] = (a.limbs || a.lora_fq) ? (a.x_pc ? a.zx[p0 + k] : a.zx[0]) : 0.f;
     }
     if (with_lora && p0 == 0) SPQ_STORE_A(0);
     __syncthreads();                                       // vmcnt(0): the panel landed; FQ(A)^T chunk gc is in LDS
@@ -652,7 +658,7 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
       {
         const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + q_row * 256 + q_pos * 16);
         const float4 sc = *reinterpret_cast<const float4*>(sxs + c * 64 + q_kof);
-        const float4 zp = *reinterpret_cast<const float4*>(sxs + XP_CHUNKS * 64 + c * 64 + q_kof);
+        const float4 zp = *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + q_kof);
         store_act4(a, q_dst + k0, v, sc, zp, qlo, qhi, pscale);
       }
       // ---- t += x . FQ(A): wave w owns k in [8w, 8w+8) of the chunk, lane half h the 4 contiguous k 8w+4h..+3
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
         float4 av = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + l31 * 256 + ((pa ^ (l31 & 15)) << 4));
         if (a.lora_fq)                                     // every element is read by exactly one lane: FQ it in place
           av = fq_act4(a, av, *reinterpret_cast<const float4*>(sxs + c * 64 + 4 * pa),
-                       *reinterpret_cast<const float4*>(sxs + XP_CHUNKS * 64 + c * 64 + 4 * pa));
+                       *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + 4 * pa));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int rb = t * 32 + l31;
@@ -1813,14 +1819,15 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   } else if (panel_ok) {
     static bool xattr = false;
     if (!xattr) {
-      hipError_t e = hipFuncSetAttribute((const void*)xpass_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP_LDS);
+      hipError_t e = hipFuncSetAttribute((const void*)xpass_panel_kernel<XP_CHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, XP_LDS);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(xpass LDS %d B): %s", XP_LDS, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
+      (void)hipFuncSetAttribute((const void*)xpass_panel_kernel<XP_CHUNKS_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, xp_lds(XP_CHUNKS_SMALL));
+      (void)hipFuncSetAttribute((const void*)xpass_panel16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP16_LDS);
       xattr = true;
     }
-    static bool x16attr = false;
-    if (!x16attr) { (void)hipFuncSetAttribute((const void*)xpass_panel16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP16_LDS); x16attr = true; }
     if (x.ascale && a->r > 0) xpass_panel16_kernel<<<xgrid, 512, XP16_LDS, st>>>(x);
-    else xpass_panel_kernel<<<xgrid, 512, XP_LDS, st>>>(x);
+    else if (xgrid >= 2 * gemm_grid(1 << 30)) xpass_panel_kernel<XP_CHUNKS_SMALL><<<xgrid, 512, xp_lds(XP_CHUNKS_SMALL), st>>>(x);
+    else xpass_panel_kernel<XP_CHUNKS><<<xgrid, 512, XP_LDS, st>>>(x);
   } else if (L.Rp <= 64) xpass_kernel<2><<<xgrid, 256, 0, st>>>(x);
   else xpass_kernel<4><<<xgrid, 256, 0, st>>>(x);
   int rc = check_launch("spq_linear_lora_fwd(xpass)");

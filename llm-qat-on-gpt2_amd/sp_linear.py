@@ -491,8 +491,9 @@ class SPLinearWithLoRA(nn.Module):
 
 
 _MFMA16 = os.environ.get('SPQ_MFMA16', '1')[:1] != '0'      # the library's kernel choice (spq_f16x2.hip)
-# x . FQ(A) of the activation pass as fp16 limbs on the f16 matrix pipe (xpass_panel16_kernel); SPQ_LORA_DOWN_F16=0: fp32-input MFMA
-_LORA_DOWN_F16 = os.environ.get('SPQ_LORA_DOWN_F16', '1') != '0'
+# SPQ_LORA_DOWN_F16=1: x . FQ(A) of the activation pass as fp16 limbs on the f16 matrix pipe (xpass_panel16_kernel).  Off by default:
+# its 200 VGPRs allow one workgroup per CU, and two resident workgroups of the fp32-MFMA kernel hide more latency
+_LORA_DOWN_F16 = os.environ.get('SPQ_LORA_DOWN_F16', '0') == '1'
 _side_streams = {}
 
 
