@@ -1,0 +1,100 @@
+"""Randomised parity sweep on the GPU: SPLinearWithLoRA forward (whatever operand path AUTO picks) against the oracle over
+random shapes, widths, quantizer types, per-channel / per-tensor, symmetric / asymmetric and input distributions.
+    python tools/fuzz_parity.py [--cases 80] [--seed 0]
+Prints one line per case and a summary; exits non-zero if any case misses |d| <= tol |y| + tol rms (tol 1e-5 minmax, 2e-5 log).
+This tool is a test: the oracle is its checker (tests/test_gpu_fuzz.py runs a short sweep of it)."""
+import argparse
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import llm_qat_on_gpt2_amd as pkg  # noqa: E402
+from oracle import ref_cpu as O  # noqa: E402
+
+DEV = 'cuda:0'
+PATHN = {1: 'f32', 2: 'f16x2', 3: 'u8x2', 4: 'f16x3'}
+
+
+def one_case(rng):
+    M = rng.choice([1, 3, 31, 32, 33, 64, 200, 257, 512, 1000, 2048])
+    K = rng.choice([4, 8, 60, 64, 72, 128, 192, 256, 320, 768, 1024, 1100])
+    N = rng.choice([4, 8, 12, 64, 100, 128, 132, 256, 384, 768])
+    r = rng.choice([0, 1, 4, 8, 16, 33, 64, 100, 128])
+    bits = rng.choice([2, 3, 4, 5, 6, 8, 10, 12, 13, 16])
+    qt = rng.choice(['minmax', 'minmax', 'log'])
+    pc = rng.random() < 0.7
+    sym = rng.random() < 0.8
+    dist = rng.choice(['normal', 'outliers', 'heavy', 'channel', 'small'])
+    seed = rng.randrange(1 << 30)
+    desc = f'M={M:4d} K={K:4d} N={N:3d} r={r:3d} {qt}{bits:2d} pc={int(pc)} sym={int(sym)} {dist:8s} seed={seed}'
+    rr = max(r, 1)
+    W, bias, A, B, x0, x1 = O.make_workload(M, K, N, rr, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    hot = rng.randrange(K)
+
+    def shape_input(x):
+        if dist == 'heavy':
+            x = x / torch.sqrt(torch.distributions.Chi2(3.0).sample(x.shape) / 3.0)
+        elif dist == 'channel':
+            x = x.clone()
+            x[:, hot] *= 60
+        elif dist == 'small':
+            x = x * 1e-3
+        elif dist == 'normal':
+            x = torch.randn(x.shape, generator=g)
+        return x.contiguous()
+
+    x0, x1 = shape_input(x0), shape_input(x1)
+    alpha = rr * rng.choice([1, 2])
+    ol = O.build_calibrated_layer(W, bias, A, B, [x0, x1], bits, qt, pc, alpha, rr, symmetric=sym)
+    layer = pkg.SPLinearWithLoRA(K, N, [bits, 32], {bits: r, 32: 0}, {bits: alpha if r else 0, 32: 0}, {bits: qt, 32: None},
+                                 per_channel=pc)
+    key = f'{bits}bit'
+    with torch.no_grad():
+        layer.linear.weight.copy_(W)
+        layer.linear.bias.copy_(bias)
+        if r:
+            layer.lora_adapters[key].lora_A.copy_(A)
+            layer.lora_adapters[key].lora_B.copy_(B)
+    layer = layer.to(DEV).eval()
+    layer.set_precision(bits)
+    if not sym:
+        qs = [layer.quantizers_input[key], layer.quantizers_weight[key]]
+        if r:
+            qs += [layer.lora_adapters[key].quantize_A, layer.lora_adapters[key].quantize_B]
+        for q in qs:
+            q.symmetric = False
+    pkg.calibrate_layer(layer, bits, [x0.to(DEV), x1.to(DEV)])
+    with torch.no_grad():
+        y = layer(x1.to(DEV)).cpu().double()
+    ref = (ol.forward(x1) if r else ol.forward(x1, calibration_mode=True)).double().reshape(y.shape)
+    tol = 1e-5 if qt == 'minmax' else 2e-5
+    rms = float(ref.pow(2).mean().sqrt())
+    worst = float(((y - ref).abs() / (tol * ref.abs() + tol * rms + 1e-30)).max())
+    ok = worst <= 1.0 and bool(torch.isfinite(y).all())
+    return ok, worst, PATHN.get(layer._last_path, '?'), desc
+
+
+def sweep(cases, seed, verbose=True):
+    rng = random.Random(seed)
+    failures = []
+    for _ in range(cases):
+        ok, worst, path, desc = one_case(rng)
+        if verbose:
+            print(f'{"ok  " if ok else "FAIL"} {desc} path={path:5s} err/bound={worst:.3f}', flush=True)
+        if not ok:
+            failures.append((desc, path, worst))
+    return failures
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', type=int, default=80)
+    ap.add_argument('--seed', type=int, default=0)
+    a = ap.parse_args()
+    bad = sweep(a.cases, a.seed)
+    print(f'{a.cases - len(bad)} of {a.cases} cases within tolerance')
+    sys.exit(1 if bad else 0)
