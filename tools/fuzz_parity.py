@@ -78,11 +78,87 @@ def one_case(rng):
     return ok, worst, PATHN.get(layer._last_path, '?'), desc
 
 
-def sweep(cases, seed, verbose=True):
+def _close(y, ref, tol):
+    y, ref = y.detach().double().cpu(), ref.detach().double().cpu().reshape(y.shape)
+    rms = float(ref.pow(2).mean().sqrt())
+    return float(((y - ref).abs() / (tol * ref.abs() + tol * rms + 1e-30)).max())
+
+
+def one_case_bwd(rng):
+    """Fused forward + straight-through backward (training mode, frozen base weight) against the oracle's closed form."""
+    M = rng.choice([32, 64, 200, 512, 1000])
+    K = rng.choice([64, 128, 192, 320, 768])
+    N = rng.choice([64, 128, 132, 384, 768])
+    r = rng.choice([4, 8, 16, 33, 64])
+    bits = rng.choice([3, 4, 6, 8, 12])
+    qt = rng.choice(['minmax', 'minmax', 'log'])
+    pc = rng.random() < 0.7
+    seed = rng.randrange(1 << 30)
+    desc = f'bwd M={M:4d} K={K:4d} N={N:3d} r={r:3d} {qt}{bits:2d} pc={int(pc)} seed={seed}'
+    W, bias, A, B, x0, x1 = O.make_workload(M, K, N, r, seed=seed)
+    g = torch.Generator().manual_seed(seed + 2)
+    # (log STE clamps gradients to [-10, 10]: with O(1) upstream gradients the clamped result hides sums of magnitude 1e3 whose
+    # fp32 summation-order noise then exceeds a bound priced on the clamped values -- in the reference's own BLAS as well)
+    gy = torch.randn(M, N, generator=g) * rng.choice([1e-3, 0.05] if qt == 'log' else [1e-3, 0.05, 1.0])
+    gy = torch.where(torch.rand(M, N, generator=g) < 1e-3, gy * 30, gy)
+    alpha = 2 * r
+    ol = O.build_calibrated_layer(W, bias, A, B, [x0, x1], bits, qt, pc, alpha, r)
+    layer = pkg.SPLinearWithLoRA(K, N, [bits, 32], {bits: r, 32: 0}, {bits: alpha, 32: 0}, {bits: qt, 32: None}, per_channel=pc)
+    key = f'{bits}bit'
+    with torch.no_grad():
+        layer.linear.weight.copy_(W); layer.linear.bias.copy_(bias)
+        layer.lora_adapters[key].lora_A.copy_(A); layer.lora_adapters[key].lora_B.copy_(B)
+    layer = layer.to(DEV).train()
+    layer.set_precision(bits)
+    pkg.calibrate_layer(layer, bits, [x0.to(DEV), x1.to(DEV)])
+    layer.linear.weight.requires_grad_(False); layer.linear.bias.requires_grad_(False)
+    xg = x1.to(DEV).requires_grad_(True)
+    layer(xg).backward(gy.to(DEV))
+    gx, gA, gB = O.sp_linear_backward(ol, x1, gy)
+    lo = layer.lora_adapters[key]
+    parts = (_close(xg.grad, gx, 2e-5), _close(lo.lora_A.grad, gA, 2e-5), _close(lo.lora_B.grad, gB, 2e-5))
+    worst = max(parts)
+    desc += ' (dx %.2f dA %.2f dB %.2f)' % parts
+    return worst <= 1.0, worst, PATHN.get(layer._last_path, '?'), desc
+
+
+def one_case_cpt(rng):
+    """part2 CPTLinear forward at a random width against the CPT oracle."""
+    from oracle import ref_cpt as C
+    M = rng.choice([3, 32, 64, 200, 512, 1000])
+    K = rng.choice([8, 64, 72, 128, 320, 768])
+    N = rng.choice([8, 64, 100, 128, 384])
+    r = rng.choice([1, 4, 16, 33, 64])
+    widths = sorted(rng.sample([2, 3, 4, 5, 6, 8, 10, 12, 16, 18], 3)) + [32]
+    qt = rng.choice(['minmax', 'log', 'log'])
+    qpb = {b: (qt if b < 32 else None) for b in widths}
+    seed = rng.randrange(1 << 30)
+    bits = rng.choice(widths[:-1])
+    desc = f'cpt M={M:4d} K={K:4d} N={N:3d} r={r:3d} {qt} widths={widths} at {bits} seed={seed}'
+    W, bias, A, B, x0, x1 = C.make_cpt_workload(M, K, N, r, seed=seed)
+    o = C.OracleCPTLayer(W, bias, A, B, widths, qpb, rank=r, alpha=2 * r)
+    m = pkg.CPTLinear(K, N, bit_widths=widths, quantizer_per_bit=qpb, shared_lora_rank=r, shared_lora_alpha=2 * r)
+    with torch.no_grad():
+        m.linear.weight.copy_(W); m.linear.bias.copy_(bias); m.shared_lora.lora_A.copy_(A); m.shared_lora.lora_B.copy_(B)
+    m = m.to(DEV).eval()
+    for b in widths[:-1]:
+        o.calibrate(b, [x0, x1])
+        pkg.calibrate_cpt_layer(m, b, [x0.to(DEV), x1.to(DEV)])
+    o.set_precision(bits); m.set_precision(bits)
+    with torch.no_grad():
+        y = m(x1.to(DEV))
+    worst = _close(y, o.forward(x1), 1e-5 if qt == 'minmax' else 2e-5)
+    return worst <= 1.0 and bool(torch.isfinite(y).all()), worst, PATHN.get(m._last_path, '?'), desc
+
+
+CASES = {'fwd': one_case, 'bwd': one_case_bwd, 'cpt': one_case_cpt}
+
+
+def sweep(cases, seed, verbose=True, mode='fwd'):
     rng = random.Random(seed)
     failures = []
     for _ in range(cases):
-        ok, worst, path, desc = one_case(rng)
+        ok, worst, path, desc = CASES[mode](rng)
         if verbose:
             print(f'{"ok  " if ok else "FAIL"} {desc} path={path:5s} err/bound={worst:.3f}', flush=True)
         if not ok:
@@ -94,7 +170,8 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=80)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--mode', choices=sorted(CASES), default='fwd')
     a = ap.parse_args()
-    bad = sweep(a.cases, a.seed)
+    bad = sweep(a.cases, a.seed, mode=a.mode)
     print(f'{a.cases - len(bad)} of {a.cases} cases within tolerance')
     sys.exit(1 if bad else 0)
