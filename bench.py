@@ -140,14 +140,17 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             y = layer(x)
-        ev = HipEvents(args.steps)
+        EVERY = int(os.environ.get('SPQ_BENCH_EVENT_EVERY', '8'))
+        ev = HipEvents((args.steps + EVERY - 1) // EVERY)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            layer._gemm_events = ev.pairs[i]
+            # the dominant kernel is timed live on every EVERY-th step of the timed region: an event pair costs two marker
+            # packets on the launch stream, and on every step that alone took 8 % off the throughput it was meant to explain
+            layer._gemm_events = ev.pairs[i // EVERY] if i % EVERY == 0 else None
             y = layer(x)
         torch.cuda.synchronize()
         if world > 1:
@@ -225,7 +228,7 @@ def main():
                          else "gemm_f32_nt (dense contraction + LoRA-up + bias)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "peak_dtype": "f16 dense MFMA (2 limb products per algorithmic product)" if is_f16
+                         "kernel_launches_timed": len(gemm_ms), "peak_dtype": "f16 dense MFMA (2 limb products per algorithmic product)" if is_f16
                          else "f32-input MFMA", "kernel_ms_avg": round(gemm_avg_ms, 4),
                          "frac_vs_f32_mfma_peak": round(achieved / PEAK["f32"], 4)},
         }
