@@ -389,19 +389,24 @@ class SPLinearWithLoRA(nn.Module):
                 f"Quantizer not calibrated. Please run calibration first for {qw.quantizer_type} quantizer.")
         W = self.linear.weight
         path = self._choose_path(qx, qw, lora, use_lora, quantize_input)
-        sig = [path, use_lora, _sig(W), qw._epoch, _sig(qw.scale), _sig(qw.zero_point)]
-        if path in (_lib.PATH_F16X2, _lib.PATH_U8X2, _lib.PATH_F16X3):
-            sig += [qx._epoch, _sig(qx.scale), _sig(qx.zero_point)]
+        use_cache = self.cache_operands and not self.training
         if use_lora:
-            for q, t in ((lora.quantize_A, lora.lora_A), (lora.quantize_B, lora.lora_B)):
+            for q in (lora.quantize_A, lora.quantize_B):
                 if not q.calibrated:
                     raise RuntimeError(
                         f"Quantizer not calibrated. Please run calibration first for {q.quantizer_type} quantizer.")
-                sig += [_sig(t), q._epoch, _sig(q.scale), _sig(q.zero_point)]
-        sig = tuple(sig)
+        sig = None
+        if use_cache:                                   # (training re-quantises on every call: no signature needed)
+            sig = [path, use_lora, _sig(W), qw._epoch, _sig(qw.scale), _sig(qw.zero_point)]
+            if path in (_lib.PATH_F16X2, _lib.PATH_U8X2, _lib.PATH_F16X3):
+                sig += [qx._epoch, _sig(qx.scale), _sig(qx.zero_point)]
+            if use_lora:
+                for q, t in ((lora.quantize_A, lora.lora_A), (lora.quantize_B, lora.lora_B)):
+                    sig += [_sig(t), q._epoch, _sig(q.scale), _sig(q.zero_point)]
+            sig = tuple(sig)
         ckey = (key, path)
         prep = self._prepared.get(ckey)
-        if prep is not None and prep.sig == sig and self.cache_operands and not self.training:
+        if prep is not None and use_cache and prep.sig == sig:
             return prep
         prep = prep or _Prepared()
         prep.path = path
