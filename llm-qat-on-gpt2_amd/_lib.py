@@ -135,9 +135,28 @@ def check_device(device):
 _workspaces = {}
 
 
-def workspace(device, nbytes: int) -> torch.Tensor:
+class _NoContext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CONTEXT = _NoContext()
+
+
+def on_device(device):
+    """``torch.cuda.device(device)`` only when it is not the current device already (the switch costs ~5 us per call)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_CONTEXT
+    return torch.cuda.device(idx)
+
+
+def workspace(device, nbytes: int, stream: int = None) -> torch.Tensor:
     """One grow-only scratch buffer per (device, stream); calls on one stream serialise, so layers share it."""
-    key = (device.index, stream_ptr(device))
+    key = (device.index, stream_ptr(device) if stream is None else stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

@@ -320,7 +320,8 @@ class SPLinearWithLoRA(nn.Module):
             return y.view(*lead, N)
         r = prep.r if use_lora else 0
         lib = _lib.load()
-        ws = _lib.workspace(x.device, lib.spq_fwd_workspace_bytes(M, K, N, r, prep.path))
+        st = _lib.stream_ptr(x.device)
+        ws = _lib.workspace(x.device, lib.spq_fwd_workspace_bytes(M, K, N, r, prep.path), st)
         sx = qx.scale if quantize_input else None
         zx = qx.zero_point if quantize_input else None
         if quantize_input and (sx.device != x.device or sx.numel() not in (1, K)):
@@ -343,15 +344,15 @@ class SPLinearWithLoRA(nn.Module):
         if activation == 'gelu' and prep.path in (_lib.PATH_F16X2, _lib.PATH_F16X3) and _MFMA16:
             a.epilogue = _lib.EPILOGUE_GELU
             self._activation_fused = True
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             if prep.ready is not None:                      # weight planes are being written on the side stream
                 a.stage = _lib.STAGE_ACTIVATIONS
-                rc = lib.spq_linear_lora_fwd(ctypes.byref(a), _lib.stream_ptr(x.device))
+                rc = lib.spq_linear_lora_fwd(ctypes.byref(a), st)
                 _lib.check(rc, "spq_linear_lora_fwd(activations)")
                 torch.cuda.current_stream(x.device).wait_event(prep.ready)
                 prep.ready = None
                 a.stage = _lib.STAGE_CONTRACTION
-            rc = lib.spq_linear_lora_fwd(ctypes.byref(a), _lib.stream_ptr(x.device))
+            rc = lib.spq_linear_lora_fwd(ctypes.byref(a), st)
         _lib.check(rc, "spq_linear_lora_fwd")
         return y.view(*lead, N)
 
