@@ -1351,6 +1351,195 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
 // k = 32h + 8s .. +7 on both operands (any assignment is valid as long as A and B agree), so a lane reads its A operand
 // for two MFMAs with ONE 16-byte LDS read.
 // =================================================================================================
+// -------------------------------------------------------------------------------------------------------------------
+// 128 x 128 tiles, 4 waves (2 x 2 of 64 x 64), ONE 48 KB stage buffer: 57 KB of LDS, so two workgroups share a CU and cover
+// each other's copy latency, barriers, tile prologues and epilogues (inside one workgroup of gemm_f16x2_s16_kernel those
+// phases serialise).  Per stage: wait for the copies + barrier, MFMAs, barrier, issue the next stage's copies into the same
+// buffer.  Same operand layout, same MFMA, same epilogue as the 256 x 128 kernel.
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int T128_STAGE_A = 128 * GK * 2;                 // 16 KB
+constexpr int T128_STAGE = T128_STAGE_A + 2 * STAGE_B;     // 48 KB
+constexpr int T128_LDS = T128_STAGE + 4 * EPI_WAVE;        // + 9 KB
+template <int AL, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f16x2_t128_kernel(GemmF16Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int tiles_m = g.tiles_m * 2;                        // g.tiles_m counts 256-row tiles (Mp is a multiple of 256)
+  const int nwg = tiles_m * g.tiles_n;
+  const int nl = (g.Rp / GK) * 2;
+  const int T = nl + AL * (g.Kp / GK);
+  const int gstride = (int)gridDim.x;
+  auto tile_of = [&](int p, int& bm, int& bn) {             // same XCD-aware band order, 16 tile rows per band
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = p & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (p >> 3);
+    constexpr int GROUP_M = 16;
+    const int band = wgid / (GROUP_M * g.tiles_n);
+    const int band_rows = min(GROUP_M, tiles_m - band * GROUP_M);
+    const int in_band = wgid - band * GROUP_M * g.tiles_n;
+    bm = (band * GROUP_M + in_band % band_rows) * 128;
+    bn = (in_band / band_rows) * GN;
+  };
+  const float lora_to_base = (AL == 2) ? g.xscale[0] : 1.f;
+  const float out_scale = (AL == 2) ? g.xscale[1] : 1.f;
+  int p = blockIdx.x;
+  if (p >= nwg) return;
+  int bm, bn;
+  tile_of(p, bm, bn);
+
+  const int prow = lane >> 3, pchunk = lane & 7;
+  int pc_row[4], pc_col[4];                                 // wave w owns pieces 4w..4w+3 of A and of each B limb
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { pc_row[i] = (4 * w + i) * 8 + prow; pc_col[i] = swz(pc_row[i], pchunk) * 8; }
+  auto issue = [&](int t, int tbm, int tbn) {
+    const _Float16 *A, *Bh, *Bl; int lda, ldb, k0; bool two;
+    if (t < nl) {
+      const int which = t & 1;
+      A = which ? g.tlo : g.thi; lda = g.Rp; Bh = g.Bhi; Bl = g.Blo; ldb = g.Rp; k0 = (t >> 1) * GK; two = !which;
+    } else if (AL == 1) {
+      A = g.qx; lda = g.Kp; Bh = g.Whi; Bl = g.Wlo; ldb = g.Kp; k0 = (t - nl) * GK; two = true;
+    } else {
+      const int tb = t - nl, which = tb & 1;
+      A = which ? g.xl : g.qx; lda = g.Kp; Bh = g.Whi; Bl = g.Wlo; ldb = g.Kp; k0 = (tb >> 1) * GK; two = !which;
+    }
+    const _Float16* Ab = A + (int64_t)tbm * lda + k0;
+    const _Float16* Bhb = Bh + (int64_t)tbn * ldb + k0;
+    const _Float16* Blb = Bl + (int64_t)tbn * ldb + k0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(Ab + (pc_row[i] * lda + pc_col[i]), smem + (4 * w + i) * 1024);
+      const int off = pc_row[i] * ldb + pc_col[i];
+      glds16(Bhb + off, smem + T128_STAGE_A + (4 * w + i) * 1024);
+      if (two) glds16(Blb + off, smem + T128_STAGE_A + STAGE_B + (4 * w + i) * 1024);
+    }
+  };
+
+  const int sx7 = (l15 >> 1) & 7;
+  const int fa_row = (wm * 64 + l15) * 128;
+  const int fb_row = T128_STAGE_A + (wn * 64 + l15) * 128;
+  int koff[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) koff[s] = ((4 * s + q4) ^ sx7) * 16;
+  struct Frags { f16x8 a[4], bh[4], bl[4]; };
+  f32x4 acc[4][4];
+  auto load_frags = [&](Frags& f, int s, bool two) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f.a[t] = *reinterpret_cast<const f16x8*>(smem + fa_row + t * 2048 + koff[s]);
+      f.bh[t] = *reinterpret_cast<const f16x8*>(smem + fb_row + t * 2048 + koff[s]);
+      if (two) f.bl[t] = *reinterpret_cast<const f16x8*>(smem + fb_row + STAGE_B + t * 2048 + koff[s]);
+    }
+  };
+  auto mfma_block = [&](const Frags& f, bool two) {
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
+        if (two) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[tm], f.bl[tn], acc[tm][tn], 0, 0, 0);
+      }
+  };
+  // stage: its copies were issued earlier.  Afterwards the buffer is free and the next stage (nt of tile nbm, nbn) goes in.
+  auto stage = [&](bool two, bool have_next, int nt, int nbm, int nbn) {
+    __syncthreads();                                         // vmcnt(0) + barrier: the stage has landed
+    Frags f0, f1;
+    load_frags(f0, 0, two);
+    load_frags(f1, 1, two); mfma_block(f0, two);
+    mfma_block(f1, two);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // my fragment reads are complete (and may not sink below)
+    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave has read its fragments
+    if (have_next) issue(nt, nbm, nbn);
+  };
+
+  issue(0, bm, bn);
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
+    const int pn = p + gstride;
+    const bool more = pn < nwg;
+    int nbm = 0, nbn = 0;
+    if (more) tile_of(pn, nbm, nbn);
+    float4 ep_rs[2], ep_bv[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
+      ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
+      if (n < g.N) {
+        ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);
+        if (AL == 2) { ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale; }
+        if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
+      }
+    }
+    for (int t = 0; t < nl; t += 2) {
+      stage(true, true, t + 1, bm, bn);
+      const bool last = (t + 2 == T);
+      stage(false, !last || more, last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
+    }
+    if (nl > 0) {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float ri = g.rowinv[bm + wm * 64 + tm * 16 + 4 * q4 + e];
+          if (AL == 2) ri *= lora_to_base;
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) acc[tm][tn][e] *= ri;
+        }
+    }
+    if (AL == 1) {
+      for (int t = nl; t < T; ++t) {
+        const bool last = (t + 1 == T);
+        stage(true, !last || more, last ? 0 : t + 1, last ? nbm : bm, last ? nbn : bn);
+      }
+    } else {
+      for (int t = nl; t < T; t += 2) {
+        stage(true, true, t + 1, bm, bn);
+        const bool last = (t + 2 == T);
+        stage(false, !last || more, last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
+      }
+    }
+    {                                                        // epilogue (the next tile's first stage is already in flight)
+      char* eb = smem + T128_STAGE + w * EPI_WAVE;
+      const int c4 = (lane & 7) * 4;
+      const bool interior = (bm + 128 <= g.M) && (bn + GN <= g.N);
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int n = bn + wn * 64 + tn * 32 + c4;
+        const bool n_ok = n < g.N;
+        const float4 rs = ep_rs[tn], bv = ep_bv[tn];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + l15 * 4) = acc[tm][2 * tn][e];
+            *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + (16 + l15) * 4) = acc[tm][2 * tn + 1][e];
+          }
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int r16 = it * 8 + (lane >> 3);
+            const float4 v = *reinterpret_cast<const float4*>(eb + r16 * 144 + c4 * 4);
+            const int m = bm + wm * 64 + tm * 16 + r16;
+            float4 o;
+            o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
+            if (EPI == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
+            float* dst = g.y + (int64_t)m * g.N + n;
+            if (interior) *reinterpret_cast<float4*>(dst) = o;
+            else if (n_ok && m < g.M) *reinterpret_cast<float4*>(dst) = o;
+          }
+        }
+      }
+    }
+    if (!more) break;
+    p = pn; bm = nbm; bn = nbn;
+  }
+}
+
 constexpr int U8_SLOT_A = GM * 64;                         // 16 KB (BASE: 256 x 64 B;  LORA: 256 x 32 fp16)
 constexpr int U8_SLOT_B = GN * 128;                        // 16 KB per limb (BASE: 128 x 64 fp16; LORA: 128 x 32 fp16 = 8 KB used)
 constexpr int U8_SLOT = U8_SLOT_A + 2 * U8_SLOT_B;         // 48 KB
@@ -1884,6 +2073,26 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   if (x3 && !mfma16) { set_error("spq_linear_lora_fwd: SPQ_PATH_F16X3 needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
   const bool gelu = a->epilogue == SPQ_EPILOGUE_GELU;
   if (gelu && !mfma16) { set_error("spq_linear_lora_fwd: the GELU epilogue needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
+  static int t128 = -1;
+  if (t128 < 0) {
+    const char* e = getenv("SPQ_GEMM_T128");
+    t128 = (e && e[0] == '1') ? 1 : 0;
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+  }
+  if (t128 && mfma16) {
+    const int ntiles = 2 * g.tiles_m * g.tiles_n;
+    const unsigned cus2 = 2 * gemm_grid(1 << 30);
+    const unsigned grid128 = (unsigned)ntiles < cus2 ? (unsigned)ntiles : cus2;
+    if (x3 && gelu) gemm_f16x2_t128_kernel<2, 1><<<grid128, 256, T128_LDS, st>>>(g);
+    else if (x3) gemm_f16x2_t128_kernel<2, 0><<<grid128, 256, T128_LDS, st>>>(g);
+    else if (gelu) gemm_f16x2_t128_kernel<1, 1><<<grid128, 256, T128_LDS, st>>>(g);
+    else gemm_f16x2_t128_kernel<1, 0><<<grid128, 256, T128_LDS, st>>>(g);
+    if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
+    return check_launch("spq_linear_lora_fwd(gemm_t128)");
+  }
   const unsigned grid = gemm_grid(g.tiles_m * g.tiles_n);
   if (mfma16 && x3 && gelu) gemm_f16x2_s16_kernel<0, 2, 1><<<grid, GEMM_THREADS, GEMM_LDS, st>>>(g);
   else if (mfma16 && x3) gemm_f16x2_s16_kernel<0, 2><<<grid, GEMM_THREADS, GEMM_LDS, st>>>(g);
