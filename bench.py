@@ -180,6 +180,20 @@ def main():
             elapsed_cached = time.perf_counter() - t1
         assert torch.equal(y2, y), "cached-operand forward differs from the re-quantising forward"
         layer.cache_operands = False
+    # secondary figure: L2 / Infinity-Cache cold (a 512 MB write between forwards evicts activations, weights and operands)
+    cold_ms = None
+    if world == 1:
+        flush = torch.empty(512 * 1024 * 1024 // 4, device=dev)
+        samples = []
+        with torch.no_grad():
+            for _ in range(12):
+                flush.fill_(1.0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); layer(x); e1.record(); e1.synchronize()
+                samples.append(e0.elapsed_time(e1))
+        samples.sort()
+        cold_ms = samples[len(samples) // 2]
+        del flush
     t = torch.tensor([elapsed, elapsed_cached or 0.0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,6 +238,9 @@ def main():
                 "ms_per_step": round(elapsed_cached / args.steps * 1e3, 4),
                 "value": round(world * FLOP_PER_STEP * args.steps / elapsed_cached / 1e9, 1),
                 "note": "eval-mode module: FQ(W), FQ(A), FQ(B) operands reused while unchanged; bit-identical output"},
+            "cold_caches": None if cold_ms is None else {
+                "ms_per_step": round(cold_ms, 4), "value": round(FLOP_PER_STEP / cold_ms / 1e6, 1),
+                "note": "median of 12 single forwards, each after a 512 MB write that evicts L2 and Infinity Cache; event-timed"},
             "roofline": {"bound": "mfma", "kernel": "gemm_f16x2_s16 (dense contraction + LoRA-up + bias, v_mfma_f32_16x16x32_f16)" if is_f16
                          else "gemm_f32_nt (dense contraction + LoRA-up + bias)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
