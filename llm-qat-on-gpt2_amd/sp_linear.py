@@ -211,6 +211,7 @@ class SPLinearWithLoRA(nn.Module):
         # weight-side limb split on a side stream, under the activation pass (opt-in: measured slower)
         self.overlap_prepare = os.environ.get('SPQ_OVERLAP_PREPARE', '0') == '1'
         self._bwd_gemm = None
+        self._wq_t = None                         # (signature, FQ(W)^T) for the backward, see _fq_weight_t
         self._last_t = None                       # LoRA-down product of the last training forward (consumed by autograd)
         self._activation_fused = False
         self._last_path = None                    # operand path of the most recent fused forward
@@ -237,6 +238,7 @@ class SPLinearWithLoRA(nn.Module):
     def invalidate_operand_cache(self):
         """Drop prepared operands (needed only after writing weights through ``.data`` in eval mode)."""
         self._prepared.clear()
+        self._wq_t = None
 
     # ---- forward (lora.py:127-150) ---------------------------------------------------------------------------
     def forward(self, x, activation=None):
@@ -355,6 +357,16 @@ class SPLinearWithLoRA(nn.Module):
             rc = lib.spq_linear_lora_fwd(ctypes.byref(a), st)
         _lib.check(rc, "spq_linear_lora_fwd")
         return y.view(*lead, N)
+
+    def _fq_weight_t(self, qw):
+        """FQ(W)^T, contiguous [K, N], for the backward contraction.  The base weight is frozen during QAT (main_sp.py:83), so
+        it is rebuilt only when the weight (identity, autograd version) or the weight quantizer's calibration changes."""
+        W = self.linear.weight
+        sig = (_sig(W), qw._epoch, int(qw.num_bits), _sig(qw.scale))
+        if self._wq_t is None or self._wq_t[0] != sig:
+            with torch.no_grad():
+                self._wq_t = (sig, qw(W.detach()).t().contiguous())
+        return self._wq_t[1]
 
     # ---- weight-side operands --------------------------------------------------------------------------------
     def _choose_path(self, qx, qw, lora, use_lora, quantize_input):
@@ -606,11 +618,11 @@ class _SPLinearFunction(torch.autograd.Function):
             if limbs:
                 # g . W_eff on the f16 MFMA kernel: minmax STE is the identity, so both terms share the left operand and
                 # W_eff^T = FQ(W)^T + s * FQ(A) . FQ(B)  [K, N] is formed once (0.3 GFLOP); log STE clamps the base term only
-                wq = qw(module.linear.weight.detach())
+                wq_t = module._fq_weight_t(qw)                                   # FQ(W)^T [K, N], kept while W is frozen
                 if ctx.use_lora and not log_x:
-                    w_t = torch.addmm(wq.t(), aq, bq, alpha=s)
+                    w_t = torch.addmm(wq_t, aq, bq, alpha=s)
                 else:
-                    w_t = wq.t().contiguous()
+                    w_t = wq_t
                 if module._bwd_gemm is None:
                     module._bwd_gemm = _LimbGemm()
                 if ctx.use_lora and gt is None:
