@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from . import _lib
 from .fake_quantize import LearnableFakeQuantize as _Part1FakeQuantize
 from .fake_quantize import _eps_constants, fake_quantize
-from .sp_linear import _LimbGemm, _gemm_nt, _gemm_tn, _ones, _limb_scale
+from .sp_linear import _LimbGemm, _MFMA16, _gemm_nt, _gemm_tn, _ones, _limb_scale
 
 
 class GradientQuantizer(torch.autograd.Function):
@@ -299,7 +299,7 @@ class _QuantGemm:
             return _lib.PATH_F32                       # nothing to quantize (statistics pass / uncalibrated width)
         if q.quantizer_type == 'minmax' and q.symmetric and 2 <= q.num_bits <= 12:
             return _lib.PATH_F16X2
-        return _lib.PATH_F16X3 if q.num_bits <= 24 else _lib.PATH_F32
+        return _lib.PATH_F16X3 if (q.num_bits <= 24 and _MFMA16) else _lib.PATH_F32
 
     def _buffers(self, N, K, r, dev):
         if self.key != (N, K, r, dev):

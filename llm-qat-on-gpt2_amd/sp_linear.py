@@ -104,7 +104,7 @@ class _LimbGemm:
 
     @staticmethod
     def supported(R: int, C: int) -> bool:
-        return R % 4 == 0 and R > 0 and C > 0
+        return R % 4 == 0 and R > 0 and C > 0 and _MFMA16     # SPQ_PATH_F16X3 lives in the 16x16x32 kernel
 
     def _buffers(self, R, C, device):
         if self.key != (R, C, device):
@@ -377,7 +377,7 @@ class SPLinearWithLoRA(nn.Module):
                   and shape_ok)
         # any other calibrated input quantizer (log, asymmetric, > 12 bit): FQ(x) as two fp16 limbs
         x3_ok = (quantize_input and not f16_ok and qx.quantizer_type in _lib.QTYPE_CODE and 1 <= qx.num_bits <= 16
-                 and shape_ok)
+                 and shape_ok and _MFMA16)               # the two-limb activation stages exist in the 16x16x32 kernel only
         if self.operand_path == _lib.PATH_AUTO:
             return _lib.PATH_F16X2 if f16_ok else (_lib.PATH_F16X3 if x3_ok else _lib.PATH_F32)
         if self.operand_path == _lib.PATH_F16X3:
