@@ -295,7 +295,7 @@ class _QuantGemm:
 
     @staticmethod
     def path_for(q, N, quantize):
-        if not quantize or N % 4 != 0:
+        if not quantize or (N % 4 != 0 and not _MFMA16):
             return _lib.PATH_F32                       # nothing to quantize (statistics pass / uncalibrated width)
         if q.quantizer_type == 'minmax' and q.symmetric and 2 <= q.num_bits <= 12:
             return _lib.PATH_F16X2

@@ -1133,6 +1133,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
   const int nl = (g.Rp / GK) * 2;           // LoRA stages per tile
   const int T = nl + AL * (g.Kp / GK);      // stages per tile
   const int gstride = (int)gridDim.x;
+  const bool vecN = (g.N & 3) == 0;        // 16-B aligned output rows (the usual case); otherwise scalar stores
 
   // XCD-aware tile order (speed only): positions of one XCD (p % 8, observed round-robin placement) map to a
   // contiguous run of tiles that walks the tile grid in bands of 8 tile-rows, column by column, so the ~32 tiles an
@@ -1253,9 +1254,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
       const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
       ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
       if (n < g.N) {
-        ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);
+        ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);            // rowscale has Np entries
         if (AL == 2) { ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale; }   // exact
-        if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
+        if (g.bias) {
+          if (vecN) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
+          else {                                                                 // N % 4 != 0: the last group is ragged
+            ep_bv[tn].x = g.bias[n];
+            if (n + 1 < g.N) ep_bv[tn].y = g.bias[n + 1];
+            if (n + 2 < g.N) ep_bv[tn].z = g.bias[n + 2];
+            if (n + 3 < g.N) ep_bv[tn].w = g.bias[n + 3];
+          }
+        }
       }
     }
 
@@ -1295,7 +1304,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
     {
       char* eb = smem + 2 * STAGE_BYTES + w * EPI_WAVE;
       const int c4 = (lane & 7) * 4;                     // 8 lanes x 16 B per 128-B row
-      const bool interior = (bm + GM <= g.M) && (bn + GN <= g.N);
+      const bool interior = vecN && (bm + GM <= g.M) && (bn + GN <= g.N);
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
         const int n = bn + wn * 64 + tn * 32 + c4;
@@ -1320,7 +1329,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
               float* dst = g.y + (int64_t)m * g.N + n;
               if (DIAG & 4) { if (v.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }
               else if (interior) *reinterpret_cast<float4*>(dst) = o;
-              else if (n_ok && m < g.M) *reinterpret_cast<float4*>(dst) = o;
+              else if (n_ok && m < g.M) {
+                if (vecN) *reinterpret_cast<float4*>(dst) = o;
+                else {                                   // rows of y are not 16-B aligned: scalar stores, ragged tail
+                  dst[0] = o.x;
+                  if (n + 1 < g.N) dst[1] = o.y;
+                  if (n + 2 < g.N) dst[2] = o.z;
+                  if (n + 3 < g.N) dst[3] = o.w;
+                }
+              }
             }
           }
       }
@@ -1940,7 +1957,7 @@ static PrepLayout make_prep_layout(int64_t N, int64_t K, int64_t r) {
 }
 
 static bool f16x2_shape_ok(int64_t M, int64_t K, int64_t N, int64_t r) {
-  return r <= 128 && (N % 4 == 0) && M < (1 << 30) && N < (1 << 30) && K < (1 << 30);
+  return r <= 128 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30);
 }
 
 // persistent grid: one workgroup per CU (a multiple of 8 so that p % 8 stays the XCD label across iterations)
@@ -1968,7 +1985,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     return SPQ_ERR_UNSUPPORTED;
   }
   if (!f16x2_shape_ok(a->M, a->K, a->N, a->r)) {
-    set_error("spq_linear_lora_fwd: SPQ_PATH_F16X2 needs LoRA rank <= 128 and N %% 4 == 0 (got r=%lld N=%lld)", (long long)a->r, (long long)a->N);
+    set_error("spq_linear_lora_fwd: the F16 operand paths need LoRA rank <= 128 (got r=%lld)", (long long)a->r);
     return SPQ_ERR_UNSUPPORTED;
   }
   SPQ_REQUIRE(a->w_rowscale, "spq_linear_lora_fwd: w_rowscale missing for SPQ_PATH_F16X2");
@@ -1996,6 +2013,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 needs an input quantizer of at most 8 bits (got %d)", a->bits);
     return SPQ_ERR_UNSUPPORTED;
   }
+  if (a->path == SPQ_PATH_U8X2 && (a->N & 3) != 0) { set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 needs N %% 4 == 0"); return SPQ_ERR_UNSUPPORTED; }
   if (a->path == SPQ_PATH_U8X2 && a->epilogue != SPQ_EPILOGUE_NONE) { set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 has no fused epilogue"); return SPQ_ERR_UNSUPPORTED; }
   const bool a8 = a->path == SPQ_PATH_U8X2;   // levels as bytes + 3-slot ring kernel (opt-in)
   x.a8 = a8 ? 1 : 0;
@@ -2082,7 +2100,8 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
   }
-  if (t128 && mfma16) {
+  if ((a->N & 3) != 0 && !mfma16) { set_error("spq_linear_lora_fwd: N %% 4 != 0 needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
+  if (t128 && mfma16 && (a->N & 3) == 0) {
     const int ntiles = 2 * g.tiles_m * g.tiles_n;
     const unsigned cus2 = 2 * gemm_grid(1 << 30);
     const unsigned grid128 = (unsigned)ntiles < cus2 ? (unsigned)ntiles : cus2;
@@ -2124,7 +2143,7 @@ extern "C" int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const flo
   SPQ_REQUIRE(r == 0 || (B && sb && zb), "spq_prepare_f16x2: LoRA operands missing");
   SPQ_REQUIRE(!A || (sa && za && a_prep), "spq_prepare_f16x2: LoRA-A quantizer parameters / output missing");
   SPQ_REQUIRE(w_bits >= 1 && b_bits >= 0 && a_bits >= 0, "spq_prepare_f16x2: bad bit-width");
-  if (!f16x2_shape_ok(1, K, N, r)) { set_error("spq_prepare_f16x2: needs LoRA rank <= 128 and N %% 4 == 0 (got r=%lld N=%lld)", (long long)r, (long long)N); return SPQ_ERR_UNSUPPORTED; }
+  if (!f16x2_shape_ok(1, K, N, r)) { set_error("spq_prepare_f16x2: needs LoRA rank <= 128 (got r=%lld)", (long long)r); return SPQ_ERR_UNSUPPORTED; }
   const PrepLayout P = make_prep_layout(N, K, r);
   if (w_prep_bytes < P.total || !aligned16(w_prep)) { set_error("spq_prepare_f16x2: buffer too small (%zu < %zu)", w_prep_bytes, P.total); return SPQ_ERR_WORKSPACE; }
   char* wp = (char*)w_prep;

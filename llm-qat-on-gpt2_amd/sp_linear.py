@@ -104,7 +104,7 @@ class _LimbGemm:
 
     @staticmethod
     def supported(R: int, C: int) -> bool:
-        return R % 4 == 0 and R > 0 and C > 0 and _MFMA16     # SPQ_PATH_F16X3 lives in the 16x16x32 kernel
+        return R > 0 and C > 0 and _MFMA16                  # SPQ_PATH_F16X3 lives in the 16x16x32 kernel
 
     def _buffers(self, R, C, device):
         if self.key != (R, C, device):
@@ -372,7 +372,7 @@ class SPLinearWithLoRA(nn.Module):
     def _choose_path(self, qx, qw, lora, use_lora, quantize_input):
         """SPQ_PATH_F16X2 (exact integer levels x 2-limb fp16 weights) whenever the input quantizer allows it:
         symmetric minmax, <= 12 bits, actually quantising; otherwise the always-valid fp32-MFMA path."""
-        shape_ok = (not use_lora or lora.rank <= 128) and self.out_features % 4 == 0
+        shape_ok = (not use_lora or lora.rank <= 128) and (self.out_features % 4 == 0 or _MFMA16)
         f16_ok = (quantize_input and qx.quantizer_type == 'minmax' and qx.symmetric and 2 <= qx.num_bits <= 12
                   and shape_ok)
         # any other calibrated input quantizer (log, asymmetric, > 12 bit): FQ(x) as two fp16 limbs

@@ -61,6 +61,9 @@ SHAPES = [
     ("bits13_two_limbs",   256,  128,  128,  16, 13, "minmax", True),
     ("bits16_two_limbs",   256,  128,  128,  16, 16, "minmax", False),
     ("log4_per_tensor",    512,  256,  256,  32, 4, "log",    False),
+    ("ragged_N_101",       300,  128,  101,  16, 4, "minmax", True),      # N % 4 != 0: scalar stores in the contraction's epilogue
+    ("ragged_N_50_log",    257,  64,   50,   8,  6, "log",    True),
+    ("vocab_like_N_1003",  512,  256,  1003, 16, 8, "minmax", True),
 ]
 
 

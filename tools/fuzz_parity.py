@@ -21,7 +21,7 @@ PATHN = {1: 'f32', 2: 'f16x2', 3: 'u8x2', 4: 'f16x3'}
 def one_case(rng):
     M = rng.choice([1, 3, 31, 32, 33, 64, 200, 257, 512, 1000, 2048])
     K = rng.choice([4, 8, 60, 64, 72, 128, 192, 256, 320, 768, 1024, 1100])
-    N = rng.choice([4, 8, 12, 64, 100, 128, 132, 256, 384, 768])
+    N = rng.choice([4, 8, 12, 50, 64, 100, 101, 128, 132, 256, 384, 768])
     r = rng.choice([0, 1, 4, 8, 16, 33, 64, 100, 128])
     bits = rng.choice([2, 3, 4, 5, 6, 8, 10, 12, 13, 16])
     qt = rng.choice(['minmax', 'minmax', 'log'])
@@ -88,7 +88,7 @@ def one_case_bwd(rng):
     """Fused forward + straight-through backward (training mode, frozen base weight) against the oracle's closed form."""
     M = rng.choice([32, 64, 200, 512, 1000])
     K = rng.choice([64, 128, 192, 320, 768])
-    N = rng.choice([64, 128, 132, 384, 768])
+    N = rng.choice([64, 101, 128, 132, 384, 768])
     r = rng.choice([4, 8, 16, 33, 64])
     bits = rng.choice([3, 4, 6, 8, 12])
     qt = rng.choice(['minmax', 'minmax', 'log'])
@@ -127,7 +127,7 @@ def one_case_cpt(rng):
     from oracle import ref_cpt as C
     M = rng.choice([3, 32, 64, 200, 512, 1000])
     K = rng.choice([8, 64, 72, 128, 320, 768])
-    N = rng.choice([8, 64, 100, 128, 384])
+    N = rng.choice([8, 50, 64, 100, 101, 128, 384])
     r = rng.choice([1, 4, 16, 33, 64])
     widths = sorted(rng.sample([2, 3, 4, 5, 6, 8, 10, 12, 16, 18], 3)) + [32]
     qt = rng.choice(['minmax', 'log', 'log'])
