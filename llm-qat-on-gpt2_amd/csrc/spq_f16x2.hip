@@ -692,6 +692,153 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------------------
+// 16-row variant for small M (fewer than two 32-row blocks per CU): 16 rows x 8 chunks per panel (68 KB of LDS, 256 threads), so
+// two workgroups share a CU where the 32-row kernel leaves it one, and they cover each other's load phases and per-chunk
+// latency chains (the pass costs half as much per row once a CU holds two workgroups: 21 -> 10 us per 8192 x 768 rows).
+// LoRA-down on v_mfma_f32_16x16x4_f32: wave w owns k in [16w, 16w+16) of a chunk, lane quarter q its 4 contiguous k.
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int XR16 = 16, XP16R_CH = 8;
+constexpr int XP16R_XS = XP16R_CH * XR16 * 256;             // 32 KB
+constexpr int XP16R_LDS = XP16R_XS + XP_NAS * XP_AS + 2 * XP16R_CH * 64 * 4;   // + 32 KB + 4 KB
+__global__ __launch_bounds__(256, 2) void xpass_rows16_kernel(XPassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char xsm[];
+  constexpr int CH = XP16R_CH;
+  char* xs = xsm;
+  char* as = xsm + XP16R_XS;
+  float* sxs = reinterpret_cast<float*>(xsm + XP16R_XS + XP_NAS * XP_AS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * XR16;
+  const float qhi = (float)((1 << (a.bits - 1)) - 1), qlo = -qhi;
+  const float pscale = a.limbs ? a.xscale[0] : 1.f;
+  const bool with_lora = a.r > 0;
+  const int l15 = lane & 15, q4 = lane >> 4;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+
+  // x copy: a 64-column chunk of the 16-row panel is 4 pieces of 1 KB (4 rows x 256 B); wave w issues piece w
+  const int prow = w * 4 + (lane >> 4), ppos = lane & 15;
+  const float* x_src = a.x + (int64_t)min(m0 + prow, a.M - 1) * a.K + ((ppos ^ (prow & 15)) << 2);
+  const int q_row = tid >> 4, q_pos = tid & 15;
+  const int q_kof = (q_pos ^ (q_row & 15)) << 2;
+  const int64_t q_dst = (int64_t)min(m0 + q_row, a.M - 1) * a.Kp + q_kof;
+
+  // FQ(A)^T chunk [64 j x 64 k] fp32: thread -> rows a_r, a_r+16, a_r+32, a_r+48, 16-B source chunk a_c; register staged
+  const int total_chunks = a.K / 64;
+  float4 ra[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int a_r = tid >> 4, a_c = tid & 15;
+  const float* a_src = a.aT + (int64_t)a_r * a.K + (a_c << 2);
+  const int64_t a_step = (int64_t)16 * a.K;
+  const int a_dst = a_r * 256 + ((a_c ^ (a_r & 15)) << 4);       // (a_r + 16 i) & 15 == a_r & 15
+#define SPQ_LOAD_A(k0)                                                                                       \
+  do {                                                                                                       \
+    ra[0] = *reinterpret_cast<const float4*>(a_src + (k0));                                                  \
+    ra[1] = *reinterpret_cast<const float4*>(a_src + a_step + (k0));                                         \
+    ra[2] = *reinterpret_cast<const float4*>(a_src + 2 * a_step + (k0));                                     \
+    ra[3] = *reinterpret_cast<const float4*>(a_src + 3 * a_step + (k0));                                     \
+  } while (0)
+#define SPQ_STORE_A(buf)                                                                                     \
+  do {                                                                                                       \
+    char* d_ = as + (buf) * XP_AS + a_dst;                                                                   \
+    *reinterpret_cast<float4*>(d_) = ra[0];                                                                  \
+    *reinterpret_cast<float4*>(d_ + 16 * 256) = ra[1];                                                       \
+    *reinterpret_cast<float4*>(d_ + 32 * 256) = ra[2];                                                       \
+    *reinterpret_cast<float4*>(d_ + 48 * 256) = ra[3];                                                       \
+  } while (0)
+
+  int gc = 0;
+  if (with_lora) SPQ_LOAD_A(0);
+  for (int p0 = 0; p0 < a.K; p0 += CH * 64) {
+    const int nch = min(CH, (a.K - p0) / 64);
+    for (int c = 0; c < nch; ++c) glds16(x_src + p0 + c * 64, xs + c * (XR16 * 256) + w * 1024);
+    for (int k = tid; k < nch * 64; k += 256) {
+      sxs[k] = a.x_pc ? a.sx[p0 + k] : a.sx[0];
+      sxs[CH * 64 + k] = (a.limbs || a.lora_fq) ? (a.x_pc ? a.zx[p0 + k] : a.zx[0]) : 0.f;
+    }
+    if (with_lora && p0 == 0) SPQ_STORE_A(0);
+    __syncthreads();                                       // vmcnt(0): the panel landed; FQ(A)^T chunk gc is in LDS
+    for (int c = 0; c < nch; ++c, ++gc) {
+      const int k0 = p0 + c * 64;
+      const bool next_a = with_lora && gc + 1 < total_chunks;
+      if (next_a) SPQ_LOAD_A((gc + 1) * 64);
+      {
+        const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR16 * 256) + q_row * 256 + q_pos * 16);
+        const float4 sc = *reinterpret_cast<const float4*>(sxs + c * 64 + q_kof);
+        const float4 zp = *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + q_kof);
+        store_act4(a, q_dst + k0, v, sc, zp, qlo, qhi, pscale);
+      }
+      if (with_lora) {
+        const int pa = 4 * w + q4;                         // 16-B source chunk of this lane: k = 16 w + 4 q4 .. + 3
+        float4 av = *reinterpret_cast<const float4*>(xs + c * (XR16 * 256) + l15 * 256 + ((pa ^ l15) << 4));
+        if (a.lora_fq)
+          av = fq_act4(a, av, *reinterpret_cast<const float4*>(sxs + c * 64 + 4 * pa),
+                       *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + 4 * pa));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int rb = t * 16 + l15;
+          const float4 bv = *reinterpret_cast<const float4*>(as + (gc & 1) * XP_AS + rb * 256 + ((pa ^ (rb & 15)) << 4));
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[t], 0, 0, 0);
+        }
+        if (next_a) SPQ_STORE_A((gc + 1) & 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    __syncthreads();
+  }
+#undef SPQ_LOAD_A
+#undef SPQ_STORE_A
+  if (!with_lora) return;
+  // ---- finish: sum the 4 per-wave k-partials (fixed order), per-row power-of-two scale, two fp16 limbs (+ t_out)
+  float* red = reinterpret_cast<float*>(xsm);              // [4][16][64] floats = 16 KB, panel images are free
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(w * XR16 + 4 * q4 + e) * 64 + t * 16 + l15] = acc[t][e];   // C/D: col = lane&15, row = 4 (lane>>4) + e
+  __syncthreads();
+  const int row = tid >> 4, c0 = (tid & 15) * 4;
+  float tv[4];
+  float rmax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float s01 = red[(0 * XR16 + row) * 64 + c0 + j] + red[(1 * XR16 + row) * 64 + c0 + j];
+    const float s23 = red[(2 * XR16 + row) * 64 + c0 + j] + red[(3 * XR16 + row) * 64 + c0 + j];
+    tv[j] = s01 + s23;
+    rmax = fmaxf(rmax, fabsf(tv[j]));
+  }
+  rmax = fmaxf(rmax, __shfl_xor(rmax, 1, 64)); rmax = fmaxf(rmax, __shfl_xor(rmax, 2, 64));
+  rmax = fmaxf(rmax, __shfl_xor(rmax, 4, 64)); rmax = fmaxf(rmax, __shfl_xor(rmax, 8, 64));
+  const float p = pow2_scale_for(rmax);
+  const int m = m0 + row;
+  if (m < a.M) {
+    if ((tid & 15) == 0) a.rowinv[m] = 1.0f / p;
+    union { _Float16 hh[4]; uint2 u; } hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2(tv[j] * p, hi.hh[j], lo.hh[j]);
+    *reinterpret_cast<uint2*>(a.thi + (int64_t)m * a.Rp + c0) = hi.u;
+    *reinterpret_cast<uint2*>(a.tlo + (int64_t)m * a.Rp + c0) = lo.u;
+    if (a.t_out) {
+      float* to = a.t_out + (int64_t)m * a.r + c0;
+      if ((a.r & 3) == 0 && c0 + 4 <= a.r) *reinterpret_cast<float4*>(to) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (c0 + j < a.r) to[j] = tv[j];
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
 // The same pass with the LoRA-down product on the f16 matrix pipe (fp32-input MFMA runs at 1/16 of its rate and was half of
 // this kernel's time at K = 3072).  x has no calibrated bound, so each 32-row panel gets per-row powers of two 2^g[m] from
 // its own row maxima (one LDS sweep), x * 2^g and FQ(A)^T * 2^S are split into two fp16 limbs on the fly (S from the LoRA-A
@@ -2032,7 +2179,15 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)xpass_panel16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP16_LDS);
       xattr = true;
     }
+    static int rows16 = -1;
+    if (rows16 < 0) {
+      const char* e = getenv("SPQ_XPASS_ROWS16");
+      rows16 = (e && e[0] == '0') ? 0 : 1;
+      (void)hipFuncSetAttribute((const void*)xpass_rows16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP16R_LDS);
+    }
     if (x.ascale && a->r > 0) xpass_panel16_kernel<<<xgrid, 512, XP16_LDS, st>>>(x);
+    else if (rows16 && xgrid < 2 * gemm_grid(1 << 30))
+      xpass_rows16_kernel<<<(unsigned)((a->M + XR16 - 1) / XR16), 256, XP16R_LDS, st>>>(x);
     else if (xgrid >= 2 * gemm_grid(1 << 30)) xpass_panel_kernel<XP_CHUNKS_SMALL><<<xgrid, 512, xp_lds(XP_CHUNKS_SMALL), st>>>(x);
     else xpass_panel_kernel<XP_CHUNKS><<<xgrid, 512, XP_LDS, st>>>(x);
   } else if (L.Rp <= 64) xpass_kernel<2><<<xgrid, 256, 0, st>>>(x);
