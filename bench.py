@@ -241,7 +241,7 @@ def main():
             "cold_caches": None if cold_ms is None else {
                 "ms_per_step": round(cold_ms, 4), "value": round(FLOP_PER_STEP / cold_ms / 1e6, 1),
                 "note": "median of 12 single forwards, each after a 512 MB write that evicts L2 and Infinity Cache; event-timed"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f16x2_s16 (dense contraction + LoRA-up + bias, v_mfma_f32_16x16x32_f16)" if is_f16
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16x2_t128 / gemm_f16x2_s16 (dense contraction + LoRA-up + bias, v_mfma_f32_16x16x32_f16)" if is_f16
                          else "gemm_f32_nt (dense contraction + LoRA-up + bias)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,

@@ -2249,14 +2249,17 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   static int t128 = -1;
   if (t128 < 0) {
     const char* e = getenv("SPQ_GEMM_T128");
-    t128 = (e && e[0] == '1') ? 1 : 0;
+    t128 = !e ? 2 : (e[0] == '1' ? 1 : 0);     // unset: by shape (below), 1: always, 0: never
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
   }
   if ((a->N & 3) != 0 && !mfma16) { set_error("spq_linear_lora_fwd: N %% 4 != 0 needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
-  if (t128 && mfma16 && (a->N & 3) == 0) {
+  // measured (tools/config_bench.py): two decoupled 128x128 workgroups per CU win 1.5-3 % while M <= 8192 and lose 3-6 % at
+  // M = 32768 and on the three-product path (1.5x the copy traffic)
+  const bool use_t128 = t128 == 1 || (t128 == 2 && !x3 && a->M <= 12288);
+  if (use_t128 && mfma16 && (a->N & 3) == 0) {
     const int ntiles = 2 * g.tiles_m * g.tiles_n;
     const unsigned cus2 = 2 * gemm_grid(1 << 30);
     const unsigned grid128 = (unsigned)ntiles < cus2 ? (unsigned)ntiles : cus2;
