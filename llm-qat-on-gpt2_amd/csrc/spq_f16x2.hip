@@ -1524,6 +1524,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
 constexpr int T128_STAGE_A = 128 * GK * 2;                 // 16 KB
 constexpr int T128_STAGE = T128_STAGE_A + 2 * STAGE_B;     // 48 KB
 constexpr int T128_LDS = T128_STAGE + 4 * EPI_WAVE;        // + 9 KB
+#ifndef T128_GROUP_M
+#define T128_GROUP_M 8      // measured at the headline shape: 8 -> 81.5 us, 16 -> 82.9, 32 -> 84.5, 4 -> 84.5
+#endif
 template <int AL, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f16x2_t128_kernel(GemmF16Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1536,10 +1539,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_t128_kernel(GemmF16Args g) 
   const int nl = (g.Rp / GK) * 2;
   const int T = nl + AL * (g.Kp / GK);
   const int gstride = (int)gridDim.x;
-  auto tile_of = [&](int p, int& bm, int& bn) {             // same XCD-aware band order, 16 tile rows per band
+  auto tile_of = [&](int p, int& bm, int& bn) {             // same XCD-aware band order, T128_GROUP_M tile rows per band
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = p & 7;
     const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (p >> 3);
-    constexpr int GROUP_M = 16;
+    constexpr int GROUP_M = T128_GROUP_M;
     const int band = wgid / (GROUP_M * g.tiles_n);
     const int band_rows = min(GROUP_M, tiles_m - band * GROUP_M);
     const int in_band = wgid - band * GROUP_M * g.tiles_n;
