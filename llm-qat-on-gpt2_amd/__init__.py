@@ -11,9 +11,9 @@ from .sp_linear import LoRALayer, SPLinearWithLoRA
 from .calibration import SpqComm, allreduce_calibration_stats, calibrate_layer, calibrate_model
 from . import cpt, synthetic
 from .blocks import SPMLP, SPAttention, SPBlock, SwitchableLayerNorm
-from .cpt import CPTLinear, LoRAAdapter, GradientQuantizer, calibrate_cpt_layer
+from .cpt import CPTLinear, LoRAAdapter, GradientQuantizer, calibrate_cpt_layer, calibrate_cpt_model
 
 __all__ = ["SPLinearWithLoRA", "LoRALayer", "LearnableFakeQuantize", "MinMaxQuantizationFunction",
            "LogQuantizationFunction", "apply_minmax_quantization", "apply_log_quantization", "fake_quantize",
            "allreduce_calibration_stats", "calibrate_layer", "calibrate_model", "SpqComm",
-           "SwitchableLayerNorm", "SPMLP", "SPAttention", "SPBlock", "cpt", "CPTLinear", "LoRAAdapter", "GradientQuantizer", "calibrate_cpt_layer"]
+           "SwitchableLayerNorm", "SPMLP", "SPAttention", "SPBlock", "cpt", "CPTLinear", "LoRAAdapter", "GradientQuantizer", "calibrate_cpt_layer", "calibrate_cpt_model"]

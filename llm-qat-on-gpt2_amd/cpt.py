@@ -599,3 +599,50 @@ def calibrate_cpt_layer(layer: CPTLinear, bits: int, batches, group=None, comm=N
         ql(layer.shared_lora.lora_A); ql(layer.shared_lora.lora_B)
     ql.finish_calibration(debug=False)
     return exchanged
+
+
+def calibrate_cpt_model(model: nn.Module, bits: int, batches, forward=None, group=None, comm=None) -> int:
+    """part2's ``CalibrationManager._calibrate_precision`` + ``calibrate_lora_weight_quantizers`` (calibration.py:17-88,
+    161-203) over every ``CPTLinear`` under ``model``: weight quantizers on their weights, input quantizers through LoRA-free
+    forwards of ``batches`` (``forward(model, batch)`` defaults to ``model(batch)``), the shared LoRA quantizer of this width on
+    A then B.  Data-parallel replicas merge the input statistics with ONE all-reduce before the scales are derived.  Returns
+    the element count of that all-reduce (0 when not distributed)."""
+    from .calibration import allreduce_calibration_stats
+    if bits >= 32:
+        return 0
+    layers = [m for m in model.modules() if isinstance(m, CPTLinear)]
+    if hasattr(model, 'set_precision') and not isinstance(model, CPTLinear):
+        model.set_precision(bits)
+    for layer in layers:
+        layer.set_precision(bits)
+        qw = layer.quantizer_weight
+        qw.set_num_bits(bits); qw.start_calibration()
+        with torch.no_grad():
+            qw(layer.linear.weight.data)
+        qw.finish_calibration(debug=False)
+    started = []
+    for layer in layers:
+        qi = layer.quantizer_input
+        qi.set_num_bits(bits); qi.start_calibration()
+        layer.calibration_mode = True
+        started.append(qi)
+    try:
+        with torch.no_grad():
+            for batch in batches:
+                forward(model, batch) if forward is not None else model(batch)
+    finally:
+        for layer in layers:
+            layer.calibration_mode = False
+    exchanged = allreduce_calibration_stats(started, group, comm)
+    for qi in started:
+        qi.finish_calibration(debug=False)
+    for layer in layers:
+        if layer.shared_lora.lora_A is None:
+            continue
+        ql = layer.lora_weight_quantizers[f'{bits}bit']
+        ql.set_num_bits(bits); ql.start_calibration()
+        with torch.no_grad():
+            ql(layer.shared_lora.lora_A); ql(layer.shared_lora.lora_B)
+        ql.finish_calibration(debug=False)
+    return exchanged
+

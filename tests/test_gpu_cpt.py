@@ -129,3 +129,53 @@ def test_cpt_backward_against_reference_autograd(pkg, name):
         assert_close_y(lo.lora_A.grad, t["grad_A"], f"{name}.grad_A", 2e-5)
         assert_close_y(lo.lora_B.grad, t["grad_B"], f"{name}.grad_B", 2e-5)
     assert m.linear.weight.grad is None
+
+
+def test_calibrate_cpt_model_matches_layerwise_protocol(pkg):
+    """calibrate_cpt_model over a two-layer stack: same scales and outputs as calibrating the layers one after the other with the
+    inputs each of them sees (the second layer's calibration input is the first one's LoRA-free output, calibration.py:50-63)."""
+    torch.manual_seed(0)
+    widths, qpb = [4, 6, 32], {4: "minmax", 6: "log", 32: None}
+
+    class Two(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = pkg.CPTLinear(64, 96, bit_widths=widths, quantizer_per_bit=qpb, shared_lora_rank=8, shared_lora_alpha=16)
+            self.b = pkg.CPTLinear(96, 48, bit_widths=widths, quantizer_per_bit=qpb, shared_lora_rank=8, shared_lora_alpha=16)
+
+        def forward(self, x):
+            return self.b(torch.tanh(self.a(x)))
+
+    m1, m2 = Two().to(DEV).eval(), Two().to(DEV).eval()
+    with torch.no_grad():
+        for p1, p2 in zip(m1.parameters(), m2.parameters()):
+            if p1.dim() > 1 and p1.abs().sum() == 0:
+                p1.normal_(0, 0.02)
+            p2.copy_(p1)
+    xs = [torch.randn(4, 32, 64, device=DEV) for _ in range(3)]
+    for bits in (4, 6):
+        n = pkg.calibrate_cpt_model(m1, bits, xs[:2])
+        assert n == 0                                            # not distributed here
+        # what layer b sees during the model-level pass: layer a with calibrated weights, its input quantizer still recording
+        # (i.e. passing x through) and its LoRA branch off
+        m2.a.set_precision(bits)
+        qw = m2.a.quantizer_weight
+        qw.set_num_bits(bits); qw.start_calibration()
+        with torch.no_grad():
+            qw(m2.a.linear.weight.data)
+        qw.finish_calibration()
+        assert bits not in m2.a.quantizer_input.calibrated_bits          # eval-mode pass-through at this width
+        m2.a.calibration_mode = True
+        with torch.no_grad():
+            mids = [torch.tanh(m2.a(x)) for x in xs[:2]]
+        m2.a.calibration_mode = False
+        pkg.calibrate_cpt_layer(m2.a, bits, xs[:2])
+        pkg.calibrate_cpt_layer(m2.b, bits, mids)
+        for la, lb in ((m1.a, m2.a), (m1.b, m2.b)):
+            assert torch.equal(la.quantizer_input.scales[bits], lb.quantizer_input.scales[bits])
+            assert torch.equal(la.quantizer_weight.scales[bits], lb.quantizer_weight.scales[bits])
+            assert torch.equal(la.lora_weight_quantizers[f"{bits}bit"].scales[bits], lb.lora_weight_quantizers[f"{bits}bit"].scales[bits])
+        for mm in (m1, m2):
+            mm.a.set_precision(bits); mm.b.set_precision(bits)
+        with torch.no_grad():
+            assert torch.equal(m1(xs[2]), m2(xs[2]))
