@@ -38,10 +38,12 @@ def _worker(rank, world, port, ret):
         q1 = pkg.LearnableFakeQuantize(4, channel_dim=-1, quantizer_type="minmax", is_input=True)
         q2 = pkg.LearnableFakeQuantize(6, channel_dim=-1, quantizer_type="log", per_channel=False, is_input=True)
         q3 = pkg.LearnableFakeQuantize(8, channel_dim=0)                      # not collecting: must be left alone
-        model = torch.nn.ModuleList([q1, q2, q3])
+        # part2's quantizer (per-width scale dictionaries) takes part in the same single collective
+        q4 = pkg.cpt.LearnableFakeQuantize(6, channel_dim=-1, quantizer_type="log", is_input=True)
+        model = torch.nn.ModuleList([q1, q2, q3, q4])
         batches = [O.make_workload(64, K, 8, 4, seed=10 + 2 * r + i, batch=2)[4] for r in range(world) for i in range(2)]
         mine = batches[2 * rank:2 * rank + 2]
-        for q, log in ((q1, False), (q2, True)):
+        for q, log in ((q1, False), (q2, True), (q4, True)):
             q.start_calibration()
             # the statistics kernel is HIP-only; on CPU feed this rank's statistics from the oracle (host logic under test)
             oq = O.QuantState(q.num_bits, q.quantizer_type, -1, q.per_channel)
@@ -50,9 +52,9 @@ def _worker(rank, world, port, ret):
                 oq.observe(b)
             q.temp_min, q.temp_max, q.num_batches_collected = oq.tmin.clone(), oq.tmax.clone(), len(mine)
         n = pkg.allreduce_calibration_stats(model)
-        assert len(calls) == 1 and calls[0] == n == 2 * (K + 1), (calls, n)
+        assert len(calls) == 1 and calls[0] == n == 2 * (K + 1 + K), (calls, n)
         # expected: one process over the union of all ranks' batches
-        for q in (q1, q2):
+        for q in (q1, q2, q4):
             oq = O.QuantState(q.num_bits, q.quantizer_type, -1, q.per_channel)
             oq.start()
             for b in batches:
@@ -61,7 +63,7 @@ def _worker(rank, world, port, ret):
             assert q.temp_min.shape == oq.tmin.shape
         assert q3.temp_min is None
         # nothing collecting any more -> no collective
-        q1.collecting_stats = q2.collecting_stats = False
+        q1.collecting_stats = q2.collecting_stats = q4.collecting_stats = False
         assert pkg.allreduce_calibration_stats(model) == 0 and len(calls) == 1
         ret[rank] = "ok"
     except Exception as e:  # pragma: no cover
