@@ -203,3 +203,105 @@ class SPBlock(nn.Module):
     def _forward(self, hidden_states, attention_mask=None):
         hidden_states = hidden_states + self.attn(self.ln_1(hidden_states), attention_mask)
         return hidden_states + self.mlp(self.ln_2(hidden_states))
+
+
+class SPModel(nn.Module):
+    """models_sp.py:173-330: token + position embeddings, ``n_layer`` x SPBlock, final SwitchableLayerNorm -- the caller
+    that hosts BASELINE configs 4 / 5.  Same attribute names (``wte, wpe, drop, h, ln_f``) and state-dict keys as the
+    reference's class; ``config`` needs ``vocab_size, n_positions, n_embd, n_layer, n_head, layer_norm_epsilon, bit_widths,
+    lora_rank_per_bit, lora_alpha_per_bit, quantizer_per_bit`` (``embd_pdrop`` and ``per_channel_quantization`` optional).
+    The lm_head of ``SPLMHeadModel`` (models_sp.py:390-458) is a plain tied ``nn.Linear`` outside the quantized path and is
+    not rebuilt here."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.bit_widths = config.bit_widths
+        self.current_bit_width = max(self.bit_widths)
+        self.wte = nn.Embedding(config.vocab_size, config.n_embd)
+        self.wpe = nn.Embedding(config.n_positions, config.n_embd)
+        self.drop = nn.Dropout(getattr(config, 'embd_pdrop', 0.0))
+        self.h = nn.ModuleList([SPBlock(config, bit_widths=self.bit_widths) for _ in range(config.n_layer)])
+        self.ln_f = SwitchableLayerNorm(config.n_embd, precision_levels=self.bit_widths, eps=config.layer_norm_epsilon)
+
+    def set_precision(self, bits) -> int:
+        if bits not in self.bit_widths:
+            raise ValueError(f"Bit width {bits} not in configured widths {self.bit_widths}")
+        self.current_bit_width = bits
+        for block in self.h:
+            block.set_precision(bits)
+        self.ln_f.set_precision(bits)
+        return self.current_bit_width
+
+    def get_current_precision(self):
+        return self.current_bit_width
+
+    def disable_lora_for_calibration(self):
+        for module in self.modules():
+            if module.__class__.__name__ == 'SPLinearWithLoRA':
+                module.calibration_mode = True
+
+    def enable_lora_after_calibration(self):
+        for module in self.modules():
+            if module.__class__.__name__ == 'SPLinearWithLoRA':
+                module.calibration_mode = False
+
+    def forward(self, input_ids=None, inputs_embeds=None, attention_mask=None, use_checkpoint=False,
+                output_hidden_states=False):
+        if inputs_embeds is not None:
+            hidden_states = inputs_embeds
+        else:
+            if input_ids is None:
+                raise ValueError("Either input_ids or inputs_embeds must be provided")
+            T = input_ids.shape[1]
+            position_ids = torch.arange(0, T, dtype=torch.long, device=input_ids.device).unsqueeze(0)
+            hidden_states = self.drop(self.wte(input_ids) + self.wpe(position_ids))
+        all_hidden_states = [] if output_hidden_states else None
+        for block in self.h:
+            if output_hidden_states:
+                all_hidden_states.append(hidden_states.clone().detach())
+            hidden_states = block(hidden_states, attention_mask, use_checkpoint)
+        hidden_states = self.ln_f(hidden_states)
+        if output_hidden_states:
+            all_hidden_states.append(hidden_states.clone().detach())
+            return hidden_states, all_hidden_states
+        return hidden_states
+
+
+class SPLMHeadModel(nn.Module):
+    """models_sp.py:390-458: ``transformer`` (SPModel) + the tied, un-quantized ``lm_head`` -- the object the reference's
+    checkpoints describe (state-dict keys ``transformer.*`` + ``lm_head.weight``, deploy.py:143, main_sp_eval.py:70)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.transformer = SPModel(config)
+        self.lm_head = nn.Linear(config.n_embd, config.vocab_size, bias=False)
+        self.lm_head.weight = self.transformer.wte.weight
+
+    def set_precision(self, bits) -> int:
+        return self.transformer.set_precision(bits)
+
+    def get_current_precision(self):
+        return self.transformer.get_current_precision()
+
+    def disable_lora_for_calibration(self):
+        self.transformer.disable_lora_for_calibration()
+
+    def enable_lora_after_calibration(self):
+        self.transformer.enable_lora_after_calibration()
+
+    def forward(self, input_ids=None, inputs_embeds=None, labels=None, attention_mask=None, use_checkpoint=False,
+                output_hidden_states=False, return_dict=False):
+        out = self.transformer(input_ids, inputs_embeds=inputs_embeds, attention_mask=attention_mask,
+                               use_checkpoint=use_checkpoint, output_hidden_states=output_hidden_states)
+        hidden_states, all_hidden_states = out if output_hidden_states else (out, None)
+        logits = self.lm_head(hidden_states)
+        loss = None
+        if labels is not None:
+            shift_logits = logits[..., :-1, :].contiguous()
+            shift_labels = labels[..., 1:].contiguous()
+            loss = nn.functional.cross_entropy(shift_logits.view(-1, shift_logits.size(-1)), shift_labels.view(-1))
+        if return_dict or output_hidden_states:
+            return {'loss': loss, 'logits': logits, 'hidden_states': all_hidden_states}
+        return {'loss': loss, 'logits': logits} if loss is not None else logits

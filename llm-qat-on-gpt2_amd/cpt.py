@@ -466,11 +466,31 @@ class CPTLinear(nn.Module):
             x.requires_grad or self.linear.weight.requires_grad
             or (self.linear.bias is not None and self.linear.bias.requires_grad)
             or (use_lora and (lo.lora_A.requires_grad or lo.lora_B.requires_grad)))
+        if self.training and torch.is_grad_enabled():
+            # the reference's quantizers refuse an uncalibrated width while training (part2 quantization.py:264-273); the fused
+            # path below runs with grad mode off, so the check is made here, with the caller's grad mode
+            self._require_calibrated_for_training(use_lora)
         if needs_grad:
             return _CPTLinearFunction.apply(x, self.linear.weight, self.linear.bias, lo.lora_A if use_lora else None,
                                             lo.lora_B if use_lora else None, self, use_lora)
         with torch.no_grad():
             return self._forward_fused(x, use_lora)
+
+    def _require_calibrated_for_training(self, use_lora):
+        """cpt_model.py:96-109 calls, in this order, quantizer_input, quantizer_weight and (LoRA on) the active
+        lora_weight_quantizer; each raises when its width is uncalibrated and it is not collecting."""
+        qs = [self.quantizer_input, self.quantizer_weight]
+        if use_lora:
+            qs.append(self.lora_weight_quantizers[f'{self.current_bits}bit'])
+        for q in qs:
+            if q.num_bits < 32 and not q.collecting_stats and q.num_bits not in q.calibrated_bits:
+                raise RuntimeError(
+                    f"FATAL: Quantizer not calibrated for {q.num_bits}-bit precision during training!\n"
+                    f"  Calibrated bits: {q.calibrated_bits}\n"
+                    f"  Available scales: {list(q.scales.keys())}\n"
+                    f"  Available zero_points: {list(q.zero_points.keys())}\n"
+                    f"  This indicates a bug in the calibration logic.\n"
+                    f"  Training cannot proceed with uncalibrated quantizers.")
 
     def _forward_fused(self, x, use_lora, want_t=False):
         qi = self.quantizer_input

@@ -277,6 +277,26 @@ class LearnableFakeQuantize(nn.Module):
         # note the argument order: zero_point carries log_min, scale carries log_range (:237-239)
         return apply_log_quantization(x, self.zero_point, self.scale, self.num_bits, self.symmetric)
 
+    def qparams_for(self, n_channels):
+        """``(scale, zero_point)`` in the layout the fused kernels take: one value, or one per channel (``n_channels``).
+
+        Any other shape can only be the reference's log default-fill state (quantization.py:164-172,194-197: a tensor with
+        no ``|x| > eps`` -- the zero-initialised ``lora_B`` of lora.py:38 -- gets statistics of shape ``x.shape`` with the
+        channel axis set to 1, e.g. ``[r,1]``, every entry ``log2(eps)``), which arrives here through a reference checkpoint.
+        Its entries are all equal, so it is the per-tensor quantizer of that value; anything else is refused."""
+        s, z = self.scale, self.zero_point
+        if s.numel() in (1, n_channels) and z.numel() == s.numel():
+            return s, z
+        key = (self._epoch, s.data_ptr(), s._version, z.data_ptr(), z._version)
+        cached = getattr(self, "_uniform_qparams", None)
+        if cached is None or cached[0] != key:
+            s1, z1 = s.reshape(-1)[:1].contiguous(), z.reshape(-1)[:1].contiguous()
+            uniform = bool(((s == s1).all() & (z == z1).all()).item())     # one host sync per loaded checkpoint
+            cached = self._uniform_qparams = (key, (s1, z1) if uniform else None)
+        if cached[1] is None:
+            raise RuntimeError(f"scale of shape {tuple(s.shape)} does not fit {n_channels} channels")
+        return cached[1]
+
     def quantize_levels(self, x):
         """Integer levels before dequantisation (int32), for level-exactness tests and INT8 export."""
         if not self.calibrated:

@@ -324,10 +324,9 @@ class SPLinearWithLoRA(nn.Module):
         lib = _lib.load()
         st = _lib.stream_ptr(x.device)
         ws = _lib.workspace(x.device, lib.spq_fwd_workspace_bytes(M, K, N, r, prep.path), st)
-        sx = qx.scale if quantize_input else None
-        zx = qx.zero_point if quantize_input else None
-        if quantize_input and (sx.device != x.device or sx.numel() not in (1, K)):
-            raise RuntimeError(f"input scale of shape {tuple(sx.shape)} on {sx.device} does not fit input {tuple(x.shape)}")
+        sx, zx = qx.qparams_for(K) if quantize_input else (None, None)
+        if quantize_input and sx.device != x.device:
+            raise RuntimeError(f"input scale on {sx.device}, input on {x.device}")
         bias = self.linear.bias
         # training: keep the LoRA-down product x . FQ(A) for d/dB instead of recomputing it in the backward
         self._last_t = torch.empty(M, r, dtype=torch.float32, device=x.device) if (keep_t and r) else None
@@ -456,18 +455,18 @@ class SPLinearWithLoRA(nn.Module):
             r_pad = (r + 63) // 64 * 64
             if prep.a is None or tuple(prep.a.shape) != (r_pad, K) or prep.a.device != W.device:
                 prep.a = torch.zeros(r_pad, K, dtype=torch.float32, device=W.device)     # rows >= r stay zero
-            if qa.scale.numel() not in (1, r):
-                raise RuntimeError(f"LoRA-A scale of shape {tuple(qa.scale.shape)} does not fit rank {r}")
-        for q, n_expected, what in ((qw, N, "weight"), (qb, N, "LoRA-B")):
-            if q is not None and q.scale.numel() not in (1, n_expected):
-                raise RuntimeError(f"{what} scale of shape {tuple(q.scale.shape)} does not fit {n_expected} output features")
+        # (scale, zero_point) per quantizer: one value or one per channel (a reference checkpoint in the default-fill state
+        # carries other -- constant -- shapes: LearnableFakeQuantize.qparams_for)
+        sw, zw = qw.qparams_for(N)
+        sb, zb = qb.qparams_for(N) if qb is not None else (None, None)
+        sa, za = qa.qparams_for(r) if qa is not None else (None, None)
         if prep.path == _lib.PATH_F16X3:
             # no scale folding: the activation operand is FQ(x) itself, as two limbs of FQ(x) * 2^G (G from the quantizer's
             # own range bound -- FQ clamps, so the bound holds for any input); everything stays on the device
             sx_t = _ones(W.device)
             prep.x_limb_scale = _limb_scale(qx)
         else:
-            sx_t = qx.scale
+            sx_t = qx.qparams_for(K)[0]
             prep.x_limb_scale = None
         # LoRA-down product of the activation pass on the f16 matrix pipe: FQ(A)^T is split into limbs of FQ(A) * 2^S there
         prep.a_limb_scale = _limb_scale(qa) if (use_lora and _LORA_DOWN_F16 and qa.num_bits < 32) else None
@@ -480,7 +479,7 @@ class SPLinearWithLoRA(nn.Module):
         if overlap:
             with torch.cuda.device(W.device):
                 rc = lib.spq_fakequant_transposed(
-                    A.data_ptr(), K, r, qa.scale.data_ptr(), qa.zero_point.data_ptr(), 1 if qa.scale.numel() > 1 else 0,
+                    A.data_ptr(), K, r, sa.data_ptr(), za.data_ptr(), 1 if sa.numel() > 1 else 0,
                     int(qa.num_bits), _lib.QTYPE_CODE[qa.quantizer_type], 1 if qa.symmetric else 0, 1.0,
                     prep.a.data_ptr(), cur.cuda_stream)
             _lib.check(rc, "spq_fakequant_transposed")
@@ -489,14 +488,14 @@ class SPLinearWithLoRA(nn.Module):
             A = None
         with torch.cuda.device(W.device), torch.cuda.stream(side if overlap else cur):
             rc = lib.spq_prepare_f16x2(
-                W.data_ptr(), N, K, qw.scale.data_ptr(), qw.zero_point.data_ptr(), 1 if qw.scale.numel() > 1 else 0,
+                W.data_ptr(), N, K, sw.data_ptr(), zw.data_ptr(), 1 if sw.numel() > 1 else 0,
                 int(qw.num_bits), _lib.QTYPE_CODE[qw.quantizer_type], 1 if qw.symmetric else 0,
-                _lib.ptr(B), r, _lib.ptr(qb.scale) if qb else None, _lib.ptr(qb.zero_point) if qb else None,
-                (1 if qb.scale.numel() > 1 else 0) if qb else 0, int(qb.num_bits) if qb else 0,
+                _lib.ptr(B), r, _lib.ptr(sb), _lib.ptr(zb),
+                (1 if sb.numel() > 1 else 0) if qb else 0, int(qb.num_bits) if qb else 0,
                 _lib.QTYPE_CODE[qb.quantizer_type] if qb else 0, (1 if qb.symmetric else 0) if qb else 1,
                 float(lora.scaling) if use_lora else 0.0,
-                _lib.ptr(A), _lib.ptr(qa.scale) if qa else None, _lib.ptr(qa.zero_point) if qa else None,
-                (1 if qa.scale.numel() > 1 else 0) if qa else 0, int(qa.num_bits) if qa else 0,
+                _lib.ptr(A), _lib.ptr(sa), _lib.ptr(za),
+                (1 if sa.numel() > 1 else 0) if qa else 0, int(qa.num_bits) if qa else 0,
                 _lib.QTYPE_CODE[qa.quantizer_type] if qa else 0, (1 if qa.symmetric else 0) if qa else 1,
                 sx_t.data_ptr(), 1 if sx_t.numel() > 1 else 0,
                 prep.w.data_ptr(), prep.w.numel(), prep.w_rowscale.data_ptr(), _lib.ptr(prep.a) if use_lora else None,
@@ -674,14 +673,13 @@ def _fq_transposed(q: LearnableFakeQuantize, t: torch.Tensor, pad_rows_to: int =
         out = torch.zeros(out_rows, rows, dtype=torch.float32, device=t.device)
         out[:cols] = t.t()
         return out
-    per_channel = 1 if q.scale.numel() > 1 else 0
-    if per_channel and q.scale.numel() != cols:
-        raise RuntimeError(f"LoRA scale of shape {tuple(q.scale.shape)} does not fit factor {tuple(t.shape)}")
+    scale, zero_point = q.qparams_for(cols)
+    per_channel = 1 if scale.numel() > 1 else 0
     out = torch.zeros(out_rows, rows, dtype=torch.float32, device=t.device)
     tc = t.contiguous()
     with torch.cuda.device(t.device):
         rc = _lib.load().spq_fakequant_transposed(
-            tc.data_ptr(), rows, cols, q.scale.data_ptr(), q.zero_point.data_ptr(), per_channel, int(q.num_bits),
+            tc.data_ptr(), rows, cols, scale.data_ptr(), zero_point.data_ptr(), per_channel, int(q.num_bits),
             _lib.QTYPE_CODE[q.quantizer_type], 1 if q.symmetric else 0, 1.0, out.data_ptr(),
             _lib.stream_ptr(t.device))
     _lib.check(rc, "spq_fakequant_transposed")

@@ -179,3 +179,36 @@ def test_calibrate_cpt_model_matches_layerwise_protocol(pkg):
             mm.a.set_precision(bits); mm.b.set_precision(bits)
         with torch.no_grad():
             assert torch.equal(m1(xs[2]), m2(xs[2]))
+
+
+def test_training_at_an_uncalibrated_width_raises(pkg):
+    """part2 quantization.py:264-273: a quantizer asked for an uncalibrated width while training with gradients raises; in eval /
+    no-grad it passes the tensor through.  The fused layer runs its kernels with grad mode off, so the layer itself must raise."""
+    widths, qpb = [4, 6, 32], {4: "minmax", 6: "log", 32: None}
+    m = pkg.CPTLinear(64, 96, bit_widths=widths, quantizer_per_bit=qpb, shared_lora_rank=8, shared_lora_alpha=16).to(DEV)
+    with torch.no_grad():
+        m.shared_lora.lora_B.normal_(0, 0.02)
+    xs = [torch.randn(2, 16, 64, device=DEV) for _ in range(2)]
+    pkg.calibrate_cpt_layer(m, 4, xs)                                    # 6-bit is left uncalibrated
+    m.train()
+    m.set_precision(4)
+    y = m(xs[0])
+    assert y.grad_fn is not None                                         # calibrated width trains
+    m.set_precision(6)
+    with pytest.raises(RuntimeError, match="FATAL: Quantizer not calibrated for 6-bit precision during training"):
+        m(xs[0])
+    with torch.no_grad():                                                # the reference's pass-through outside training
+        y_ng = m(xs[0])
+    m.eval()
+    with torch.no_grad():
+        assert torch.equal(m(xs[0]), y_ng)
+    # only the LoRA quantizer missing: still refused while training, and only when the LoRA branch is on
+    m.train()
+    qi, qw = m.quantizer_input, m.quantizer_weight
+    for q in (qi, qw):
+        q.scales[6], q.zero_points[6] = q.scales[4], q.zero_points[4]
+        q.calibrated_bits.add(6)
+    with pytest.raises(RuntimeError, match="FATAL"):
+        m(xs[0])
+    m.calibration_mode = True
+    assert m(xs[0]).shape == (2, 16, 96)

@@ -1,0 +1,206 @@
+"""GPU parity of the multi-layer caller (BASELINE config 4's shape of work) and of the checkpoint wire format:
+
+* a 3-layer ``SPModel`` on the drop-ins against the fixture the reference's ``SPLMHeadModel`` + ``CalibrationManager`` produced
+  (tests/golden/model_sp3.npz, made by tests/golden/make_golden_model.py);
+* a checkpoint shaped like the reference's ``save_sp_checkpoints`` output, loaded the way its evaluation loader does
+  (``per_channel_quantization=False``, ``strict=True``), including log quantizers in the zero-``lora_B`` default-fill state;
+* ``convert_to_int8`` against the reference's export;
+* size-independent properties of the full GPT-2-small stack at ``set_precision(4)``, micro-batch 8 x 1024."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import llm_qat_on_gpt2_amd as p
+    p._lib.load()
+    return p
+
+
+def load_npz(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return json.loads(str(z["meta"])), {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+
+
+def make_cfg(meta, per_channel=True):
+    sp = meta["sp"]
+    ints = lambda d: {int(k): v for k, v in d.items()}
+    return types.SimpleNamespace(**meta["cfg"], bit_widths=sp["bit_widths"], lora_rank_per_bit=ints(sp["lora_rank_per_bit"]),
+                                 lora_alpha_per_bit=ints(sp["lora_alpha_per_bit"]), quantizer_per_bit=ints(sp["quantizer_per_bit"]),
+                                 per_channel_quantization=per_channel)
+
+
+def rows_off(y, ref, tol):
+    yd, yr = y.detach().cpu().double(), ref.double()
+    rms = float(yr.pow(2).mean().sqrt())
+    bad = ((yd - yr).abs() > tol * yr.abs() + tol * rms).any(dim=-1)
+    return float(bad.float().mean()), float((yd - yr).abs().max()) / rms
+
+
+@pytest.mark.parametrize("bits", [4, 6])
+def test_spmodel_stack_against_reference_fixture(pkg, bits):
+    """Embeddings + 3 x SPBlock + ln_f after ``calibrate_model`` (the CalibrationManager protocol) vs the reference model."""
+    meta, t = load_npz("model_sp3.npz")
+    model = pkg.SPModel(make_cfg(meta))
+    names = [n for n, _ in model.named_parameters()]
+    assert names == [k[len("param."):] for k in t if k.startswith("param.")], "parameter names / order differ from the reference model"
+    with torch.no_grad():
+        for n, p_ in model.named_parameters():
+            p_.copy_(t[f"param.{n}"])
+    model = model.to(DEV).eval()
+    ids = t["ids"].to(DEV)
+    calib = [t[f"calib{i}"].to(DEV) for i in range(meta["n_calib"])]
+    tol = 1e-5 if bits == 4 else 2e-5
+
+    model.set_precision(32)
+    with torch.no_grad():
+        frac, worst = rows_off(model(ids), t["y_32"], 1e-5)
+    assert frac == 0.0, f"32-bit stack: {frac:.3f} of rows off"
+
+    exchanged = pkg.calibrate_model(model, bits, calib)
+    assert exchanged == 0                                               # single process: no collective
+    key = f"{bits}bit"
+    for n in meta["linears"]:                                           # chained calibration: close, then like for like
+        q = model.get_submodule(n).quantizers_input[key]
+        ref_s = t[f"qx_{bits}.{n}.scale"]
+        assert q.scale.shape == ref_s.shape, (n, q.scale.shape, ref_s.shape)
+        # minmax: the first linear sees LayerNorm(embeddings) (a few ulp from the CPU's), later ones are downstream of GEMMs;
+        # log: the range's lower end is log2 of the smallest |x| above eps, where 1e-8 absolute is 1e-3 relative (ill-conditioned
+        # in the reference itself)
+        rtol = (2e-6 if n == "h.0.attn.c_attn" else 1e-4) if bits == 4 else 2e-3
+        assert torch.allclose(q.scale.cpu(), ref_s, rtol=rtol, atol=1e-6), n
+        with torch.no_grad():
+            q.scale = ref_s.to(DEV); q.zero_point = t[f"qx_{bits}.{n}.zero_point"].to(DEV); q._epoch += 1
+    if bits == 6:                                                       # layer 0 has the reference's zero-initialised lora_B
+        zb = model.h[0].mlp.c_fc.lora_adapters[key].quantize_B
+        assert bool((zb.scale == 0).all()) and bool((zb.zero_point == zb.zero_point.flatten()[0]).all())
+
+    n_layer = meta["cfg"]["n_layer"]
+    with torch.no_grad():
+        y, hs = model(ids, output_hidden_states=True)
+        assert len(hs) == n_layer + 1
+        # block by block from the reference's own hidden states (a level flip inside a block moves one token row by a step)
+        for i, blk in enumerate(model.h):
+            out = blk(t[f"h_{bits}_{i}"].to(DEV))
+            ref = t[f"h_{bits}_{i + 1}"] if i + 1 < n_layer else None
+            if ref is None:
+                out, ref = model.ln_f(out), t[f"y_{bits}"]
+            frac, worst = rows_off(out, ref, tol)
+            assert frac <= 0.06 and worst < 0.05, f"block {i} @ {bits}-bit: {frac:.3f} of rows off, worst {worst:.3e} rms"
+    frac, worst = rows_off(y, t[f"y_{bits}"], tol)
+    assert frac <= 0.15 and worst < 0.05, f"stack @ {bits}-bit: {frac:.3f} of rows off, worst {worst:.3e} rms"
+    # precision switching round trip and determinism
+    with torch.no_grad():
+        model.set_precision(32); model(ids); model.set_precision(bits)
+        assert torch.equal(model(ids), y)
+
+
+@pytest.mark.parametrize("bits", [4, 6])
+def test_reference_checkpoint_loads_and_runs(pkg, bits):
+    """deploy.py:125-183 file layout -> main_sp_eval.py:22-78 loader -> forward; logits against the reference's own run of the
+    same loaded model.  At 6 bit layer 0's LoRA-B quantizers carry the ``[r,1]`` default-fill statistics."""
+    from llm_qat_on_gpt2_amd import deploy
+    _, exp = load_npz("ckpt_sp3_expect.npz")
+    model, ck = deploy.load_sp_checkpoint(os.path.join(GOLDEN, f"ckpt_sp3_{bits}bit.pth"), device=DEV)
+    assert ck["bit_width"] == bits and model.get_current_precision() == bits
+    lin = model.transformer.h[0].mlp.c_fc
+    assert lin.quantizers_input[f"{bits}bit"].calibrated and lin.quantizers_weight[f"{bits}bit"].calibrated
+    assert tuple(lin.quantizers_weight[f"{bits}bit"].scale.shape) == (256, 1)          # per-channel buffers from the file
+    if bits == 6:
+        assert tuple(lin.lora_adapters["6bit"].quantize_B.scale.shape) == (8, 1)       # default-fill shape kept as loaded
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(ck["model_state_dict"].keys())
+    assert all(sd[k].shape == v.shape for k, v in ck["model_state_dict"].items())
+    ids = exp["ids"].to(DEV)
+    tol = 1e-5 if bits == 4 else 2e-5
+    with torch.no_grad():
+        hidden = model.transformer(ids)
+        logits = model(ids)
+    frac, worst = rows_off(hidden, exp[f"hidden_{bits}"], tol)
+    assert frac <= 0.15 and worst < 0.05, f"{bits}-bit checkpoint: {frac:.3f} of hidden rows off, worst {worst:.3e} rms"
+    frac, worst = rows_off(logits, exp[f"logits_{bits}"], tol)
+    assert frac <= 0.15 and worst < 0.05, f"{bits}-bit checkpoint: {frac:.3f} of logit rows off, worst {worst:.3e} rms"
+
+    # INT8 export (deploy.py:5-62): levels from spq_fakequant's int8 output
+    got = deploy.convert_to_int8(model)
+    want = {k[len(f"int8_{bits}."):]: v for k, v in exp.items() if k.startswith(f"int8_{bits}.")}
+    assert sorted(got) == sorted(want)
+    for k, v in want.items():
+        g = got[k]
+        if k.endswith("weight_int8"):
+            assert g.dtype == torch.int8 and torch.equal(g, v), k
+        elif k.endswith("scale"):
+            assert g.dtype == torch.float32 and float(g) == float(v), k
+        elif k.endswith("zero_point"):
+            assert int(g) == int(v), k
+        else:
+            assert torch.equal(g, v), k
+
+
+def test_checkpoint_round_trip_through_save(pkg, tmp_path):
+    from llm_qat_on_gpt2_amd import deploy
+    model, ck = deploy.load_sp_checkpoint(os.path.join(GOLDEN, "ckpt_sp3_4bit.pth"), device=DEV)
+    mc = types.SimpleNamespace(**ck["model_config"])
+    saved = deploy.save_sp_checkpoints(model, str(tmp_path / "sp"), mc)
+    assert sorted(saved) == [4, 6]
+    again, ck2 = deploy.load_sp_checkpoint(saved[6], device=DEV)
+    assert ck2["bit_width"] == 6 and again.get_current_precision() == 6
+    ids = torch.randint(0, 97, (2, 16), device=DEV)
+    model.set_precision(6)
+    with torch.no_grad():
+        assert torch.equal(again(ids), model(ids))
+
+
+def test_gpt2_small_stack_properties_at_full_width(pkg):
+    """BASELINE config 4's model: 12 layers, 12 heads, 768, 4-bit minmax per-channel + LoRA r=64, micro-batch 8 x 1024 tokens.
+    No reference output exists at this size (the CPU run takes minutes); size-independent properties instead."""
+    bits, r, E, T = 4, 64, 768, 1024
+    cfg = types.SimpleNamespace(vocab_size=50257, n_positions=T, n_embd=E, n_layer=12, n_head=12, layer_norm_epsilon=1e-5,
+                                embd_pdrop=0.0, bit_widths=[bits, 32], lora_rank_per_bit={bits: r, 32: 0},
+                                lora_alpha_per_bit={bits: 64, 32: 0}, quantizer_per_bit={bits: "minmax", 32: None},
+                                per_channel_quantization=True)
+    torch.manual_seed(0)
+    model = pkg.SPModel(cfg)
+    with torch.no_grad():
+        for n, p_ in model.named_parameters():
+            if "lora_B" in n:
+                p_.normal_(0, 0.01)
+            elif p_.dim() > 1 and "lora_A" not in n:
+                p_.normal_(0, 0.02)
+    model = model.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    mk = lambda n: torch.randint(0, cfg.vocab_size, (n, T), generator=g).to(DEV)
+    pkg.calibrate_model(model, bits, [mk(4) for _ in range(2)])
+    layers = [m for m in model.modules() if isinstance(m, pkg.SPLinearWithLoRA)]
+    assert len(layers) == 48 and all(m.quantizers_input[f"{bits}bit"].calibrated for m in layers)
+    assert all(tuple(m.quantizers_input[f"{bits}bit"].scale.shape) == (1, 1, m.in_features) for m in layers)
+    ids = mk(8)
+    with torch.no_grad():
+        y = model(ids)
+        assert y.shape == (8, T, E) and bool(torch.isfinite(y).all())
+        assert all(m._last_path == pkg._lib.PATH_F16X2 for m in layers)          # the MFMA limb path ran in every layer
+        assert torch.equal(model(ids), y)                                       # determinism
+        # batch-split invariance: sequences are independent (replicas over the batch see exactly this)
+        halves = torch.cat([model(ids[:4]), model(ids[4:])])
+        rms = float(y.pow(2).mean().sqrt())
+        bad = ((halves - y).abs() > 1e-5 * y.abs() + 1e-5 * rms).any(dim=-1)
+        assert float(bad.float().mean()) <= 0.01, f"{int(bad.sum())} token rows differ between batch 8 and 2 x batch 4"
+        # precision switching 4 -> 32 -> 4 (part4 switches before every forward)
+        model.set_precision(32)
+        y32 = model(ids)
+        assert not torch.allclose(y32, y, atol=1e-3)
+        model.set_precision(bits)
+        assert torch.equal(model(ids), y)
+        # random-weight 4-bit students are lossy (no training here); the output must still be of the teacher's scale
+        ratio = float(y.pow(2).mean().sqrt()) / float(y32.pow(2).mean().sqrt())
+        assert 0.2 < ratio < 5.0, ratio

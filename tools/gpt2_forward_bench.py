@@ -15,7 +15,11 @@ ap.add_argument('--layers', type=int, default=12); ap.add_argument('--embd', typ
 ap.add_argument('--bits', type=int, default=4); ap.add_argument('--qtype', default='minmax'); ap.add_argument('--seq', type=int, default=1024)
 ap.add_argument('--batch', type=int, default=256, help='sequences in the whole job (split evenly over the ranks)')
 ap.add_argument('--micro', type=int, default=32); ap.add_argument('--calib', type=int, default=10); ap.add_argument('--vocab', type=int, default=50257)
+ap.add_argument('--gpus', type=int, default=0, help='started bare with --gpus N > 1: spawn the N ranks (before any GPU call)')
 args = ap.parse_args()
+if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    import bench                                             # the launcher of bench.py: fresh child processes, no GPU call here
+    sys.exit(bench.launch_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
 world, rank, local = int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0))
 torch.cuda.set_device(local)
 dev = torch.device('cuda', local)
