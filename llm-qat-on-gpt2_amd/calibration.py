@@ -19,15 +19,13 @@ from .fake_quantize import LearnableFakeQuantize
 
 
 def _collecting_quantizers(module_or_list) -> List[LearnableFakeQuantize]:
+    """Every quantizer in statistics-collecting mode, whether or not it has seen a batch yet: module structure and the
+    ``collecting_stats`` flags are replicated, so this list is the same on every rank."""
     if isinstance(module_or_list, torch.nn.Module):
         mods = module_or_list.modules()
     else:
         mods = module_or_list
-    out = []
-    for m in mods:
-        if isinstance(m, LearnableFakeQuantize) and m.collecting_stats and m.temp_min is not None:
-            out.append(m)
-    return out
+    return [m for m in mods if isinstance(m, LearnableFakeQuantize) and m.collecting_stats]
 
 
 class SpqComm:
@@ -71,7 +69,8 @@ class SpqComm:
 
 def allreduce_calibration_stats(module_or_quantizers, group: Optional[dist.ProcessGroup] = None,
                                 comm: Optional[SpqComm] = None) -> int:
-    """Merge the running min/max of every collecting quantizer across ranks with ONE collective.
+    """Merge the running min/max of every collecting quantizer across ranks with ONE data collective (preceded by a
+    2-floats-per-quantizer agreement check, so that ranks with missing statistics fail together instead of hanging).
 
     Returns the number of fp32 elements exchanged (0 when not distributed).  Every rank must hold the same
     quantizers in the same order with the same statistic shapes (true for data-parallel replicas).
@@ -85,13 +84,37 @@ def allreduce_calibration_stats(module_or_quantizers, group: Optional[dist.Proce
         return 0
     if not qs:
         return 0
+
+    def reduce_max_(t):
+        if comm is not None:
+            comm.allreduce_max_(t)                                  # C ABI -> ncclAllReduce(ncclMax) of RCCL
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)   # backend "nccl" is RCCL on ROCm
+        return t
+
+    # Agreement check (2 floats per quantizer): a rank whose loader ran dry, or that never reached some layer, holds no -- or
+    # differently sized -- statistics; entering the data collective with a different element count would hang RCCL or merge
+    # misaligned statistics.  max(n) and max(-n) over ranks must describe the same n everywhere; every rank sees the same
+    # merged vector, so every rank raises (nobody is left waiting).
+    dev = next((q.temp_min.device for q in qs if q.temp_min is not None), None)
+    if dev is None:
+        on_gpu = comm is not None or dist.get_backend(group) == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    sizes = [float(q.temp_min.numel()) if q.temp_min is not None else 0.0 for q in qs]
+    chk = reduce_max_(torch.tensor(sizes + [-n for n in sizes], dtype=torch.float32, device=dev)).cpu()
+    hi, lo = chk[:len(qs)], -chk[len(qs):]
+    if not torch.equal(hi, lo):
+        bad = [i for i in range(len(qs)) if hi[i] != lo[i]]
+        raise RuntimeError(
+            f"calibration statistics differ in size across ranks for {len(bad)} of {len(qs)} collecting quantizers (first: #{bad[0]}, "
+            f"{int(lo[bad[0]])}..{int(hi[bad[0]])} elements, this rank {int(sizes[bad[0]])}): every rank must run the same "
+            "number (>= 1) of calibration batches through the same layers")
+    qs = [q for q, n in zip(qs, sizes) if n > 0]                    # nobody saw a batch for the others: they stay uncalibrated
+    if not qs:
+        return 0
     mins = [q.temp_min.reshape(-1) for q in qs]
     maxs = [q.temp_max.reshape(-1) for q in qs]
-    flat = torch.cat([-torch.cat(mins), torch.cat(maxs)])           # max(-min) == -min(min)
-    if comm is not None:
-        comm.allreduce_max_(flat)                                   # C ABI -> ncclAllReduce(ncclMax) of RCCL
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.MAX, group=group)    # backend "nccl" is RCCL on ROCm
+    flat = reduce_max_(torch.cat([-torch.cat(mins), torch.cat(maxs)]))       # max(-min) == -min(min)
     half = flat.numel() // 2
     off = 0
     for q in qs:

@@ -27,7 +27,14 @@ __host__ __device__ static inline bool aligned16(const void* p) { return (reinte
 // its own IEEE-754 round-to-nearest operation, like the ATen CPU kernels the reference runs on.
 
 // torch.round == round-half-to-even == rintf under the default rounding mode.
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+// torch.clamp / min / max propagate NaN; fminf / fmaxf drop it.  clampf keeps a NaN input (one compare + select), so a NaN
+// activation becomes a NaN level and a NaN output row, as in the reference.
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {
+  const float r = fminf(fmaxf(v, lo), hi);
+  return (v != v) ? v : r;
+}
+__device__ __forceinline__ float nan_min(float a, float b) { return (a != a || b != b) ? (a + b) : fminf(a, b); }
+__device__ __forceinline__ float nan_max(float a, float b) { return (a != a || b != b) ? (a + b) : fmaxf(a, b); }
 
 // quantization_methods.py:14-15 / :18-19 -- integer level (held in fp32)
 template <bool SYM>
@@ -95,7 +102,7 @@ __device__ __forceinline__ float log_level(float x, float log_min, float log_ran
   const float err = 2.4e-7f * fmaxf(fabsf(lg_fast), 1.f) * slope + 1e-6f * fmaxf(fabsf(pre), 1.f);
   const float tie_dist = 0.5f - fabsf(pre - rintf(pre));
   if (!(tie_dist > err)) pre = log_pre_round<SYM>(log2_rn(mag), log_min, log_range, p);   // also catches NaN
-  return clampf(rintf(pre), p.qlo, p.qhi);                         // :55-56 / :60-61
+  return (x != x) ? x : clampf(rintf(pre), p.qlo, p.qhi);          // :55-56 / :60-61 (a NaN input stays NaN, as torch.clamp keeps it)
 }
 // :57,:64-74 -> dequantised value
 template <bool SYM>
@@ -109,7 +116,7 @@ __device__ __forceinline__ float log_dequant(float x, float q, float log_min, fl
   else     qn = q / p.denom;                                       // :66
   float x_hat = qn * log_range + log_min;                          // :68 (unclamped range)
   float mag = __builtin_amdgcn_exp2f(x_hat);                       // :70  v_exp_f32 (<= 1 ulp, like ATen's pow); |x_hat| < 64 here
-  float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);          // :43
+  float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : ((x == 0.f) ? 0.f : x));   // :43 torch.sign (NaN -> NaN)
   float out = mag * sgn;                                           // :72
   return (fabsf(x) < 1e-5f) ? 0.f : out;                           // :41,:74
 }
@@ -123,6 +130,17 @@ __device__ __forceinline__ float wave_min(float v) {
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// NaN-propagating twins for the calibration statistics (torch's min / max reductions propagate NaN)
+__device__ __forceinline__ float wave_min_nan(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = nan_min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max_nan(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = nan_max(v, __shfl_xor(v, o, 64));
   return v;
 }
 

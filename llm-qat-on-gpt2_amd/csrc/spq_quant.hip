@@ -16,11 +16,18 @@ namespace spq {
 constexpr int kStatsBlock = 256;
 constexpr int kMaxSlabs = 256;
 
+// torch's min / max reductions propagate NaN (a diverged activation must surface as a NaN scale, not a plausible finite one);
+// v_min / v_max drop it.  The scan keeps a per-lane flag (one compare per element) and poisons its partial at the end; every
+// combine after that is NaN-propagating.
 template <bool ABS>
-__device__ __forceinline__ void acc_minmax(float v, float& lo, float& hi) {
+__device__ __forceinline__ void acc_minmax(float v, float& lo, float& hi, bool& nan) {
   if (ABS) v = fabsf(v);
+  nan |= (v != v);
   lo = fminf(lo, v);
   hi = fmaxf(hi, v);
+}
+__device__ __forceinline__ void poison(bool nan, float& lo, float& hi) {
+  if (nan) { lo = __builtin_nanf(""); hi = lo; }
 }
 
 template <bool ABS>
@@ -32,19 +39,21 @@ __global__ __launch_bounds__(kStatsBlock) void stats_rows_kernel(const float* __
   if (row >= nrows) return;
   const float* p = x + row * len;
   float lo = INFINITY, hi = -INFINITY;
+  bool nan = false;
   if ((len & 3) == 0 && aligned16(p)) {
     const float4* p4 = reinterpret_cast<const float4*>(p);
     const int64_t n4 = len >> 2;
     for (int64_t i = lane; i < n4; i += 64) {
       float4 v = p4[i];
-      acc_minmax<ABS>(v.x, lo, hi); acc_minmax<ABS>(v.y, lo, hi);
-      acc_minmax<ABS>(v.z, lo, hi); acc_minmax<ABS>(v.w, lo, hi);
+      acc_minmax<ABS>(v.x, lo, hi, nan); acc_minmax<ABS>(v.y, lo, hi, nan);
+      acc_minmax<ABS>(v.z, lo, hi, nan); acc_minmax<ABS>(v.w, lo, hi, nan);
     }
   } else {
-    for (int64_t i = lane; i < len; i += 64) acc_minmax<ABS>(p[i], lo, hi);
+    for (int64_t i = lane; i < len; i += 64) acc_minmax<ABS>(p[i], lo, hi, nan);
   }
-  lo = wave_min(lo);
-  hi = wave_max(hi);
+  poison(nan, lo, hi);
+  lo = wave_min_nan(lo);
+  hi = wave_max_nan(hi);
   if (lane == 0) { pmin[row] = lo; pmax[row] = hi; }
 }
 
@@ -60,8 +69,9 @@ __global__ __launch_bounds__(kStatsBlock) void stats_cols_kernel(const float* __
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
   const int64_t r1 = min(rows, r0 + rows_per_slab);
   float lo[W], hi[W];
+  bool nanw[W];
 #pragma unroll
-  for (int j = 0; j < W; ++j) { lo[j] = INFINITY; hi[j] = -INFINITY; }
+  for (int j = 0; j < W; ++j) { lo[j] = INFINITY; hi[j] = -INFINITY; nanw[j] = false; }
   if (c0 < cols) {
     int64_t r = r0 + ty;
     if (VEC4) {
@@ -71,29 +81,29 @@ __global__ __launch_bounds__(kStatsBlock) void stats_cols_kernel(const float* __
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (r + 4 * u) * cols + c0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          acc_minmax<ABS>(v[u].x, lo[0], hi[0]); acc_minmax<ABS>(v[u].y, lo[1 % W], hi[1 % W]);
-          acc_minmax<ABS>(v[u].z, lo[2 % W], hi[2 % W]); acc_minmax<ABS>(v[u].w, lo[3 % W], hi[3 % W]);
+          acc_minmax<ABS>(v[u].x, lo[0], hi[0], nanw[0]); acc_minmax<ABS>(v[u].y, lo[1 % W], hi[1 % W], nanw[1 % W]);
+          acc_minmax<ABS>(v[u].z, lo[2 % W], hi[2 % W], nanw[2 % W]); acc_minmax<ABS>(v[u].w, lo[3 % W], hi[3 % W], nanw[3 % W]);
         }
       }
       for (; r < r1; r += 4) {
         float4 v = *reinterpret_cast<const float4*>(x + r * cols + c0);
-        acc_minmax<ABS>(v.x, lo[0], hi[0]); acc_minmax<ABS>(v.y, lo[1 % W], hi[1 % W]);
-        acc_minmax<ABS>(v.z, lo[2 % W], hi[2 % W]); acc_minmax<ABS>(v.w, lo[3 % W], hi[3 % W]);
+        acc_minmax<ABS>(v.x, lo[0], hi[0], nanw[0]); acc_minmax<ABS>(v.y, lo[1 % W], hi[1 % W], nanw[1 % W]);
+        acc_minmax<ABS>(v.z, lo[2 % W], hi[2 % W], nanw[2 % W]); acc_minmax<ABS>(v.w, lo[3 % W], hi[3 % W], nanw[3 % W]);
       }
     } else {
-      for (; r < r1; r += 4) acc_minmax<ABS>(x[r * cols + c0], lo[0], hi[0]);
+      for (; r < r1; r += 4) acc_minmax<ABS>(x[r * cols + c0], lo[0], hi[0], nanw[0]);
     }
   }
   __shared__ float s_lo[4][64 * W], s_hi[4][64 * W];
 #pragma unroll
-  for (int j = 0; j < W; ++j) { s_lo[ty][tx * W + j] = lo[j]; s_hi[ty][tx * W + j] = hi[j]; }
+  for (int j = 0; j < W; ++j) { poison(nanw[j], lo[j], hi[j]); s_lo[ty][tx * W + j] = lo[j]; s_hi[ty][tx * W + j] = hi[j]; }
   __syncthreads();
   if (ty == 0 && c0 < cols) {
 #pragma unroll
     for (int j = 0; j < W; ++j) {
       float a = s_lo[0][tx * W + j], b = s_hi[0][tx * W + j];
 #pragma unroll
-      for (int t = 1; t < 4; ++t) { a = fminf(a, s_lo[t][tx * W + j]); b = fmaxf(b, s_hi[t][tx * W + j]); }
+      for (int t = 1; t < 4; ++t) { a = nan_min(a, s_lo[t][tx * W + j]); b = nan_max(b, s_hi[t][tx * W + j]); }
       pmin[(int64_t)blockIdx.y * cols + c0 + j] = a;
       pmax[(int64_t)blockIdx.y * cols + c0 + j] = b;
     }
@@ -108,24 +118,26 @@ __global__ __launch_bounds__(kStatsBlock) void stats_flat_kernel(const float* __
   const int64_t b0 = (int64_t)blockIdx.x * chunk;
   const int64_t b1 = min(total, b0 + chunk);
   float lo = INFINITY, hi = -INFINITY;
+  bool nan = false;
   if ((chunk & 3) == 0 && aligned16(x)) {
     const int64_t e4 = b0 + ((b1 - b0) & ~(int64_t)3);
     for (int64_t i = b0 + (int64_t)threadIdx.x * 4; i < e4; i += kStatsBlock * 4) {
       float4 v = *reinterpret_cast<const float4*>(x + i);
-      acc_minmax<ABS>(v.x, lo, hi); acc_minmax<ABS>(v.y, lo, hi);
-      acc_minmax<ABS>(v.z, lo, hi); acc_minmax<ABS>(v.w, lo, hi);
+      acc_minmax<ABS>(v.x, lo, hi, nan); acc_minmax<ABS>(v.y, lo, hi, nan);
+      acc_minmax<ABS>(v.z, lo, hi, nan); acc_minmax<ABS>(v.w, lo, hi, nan);
     }
-    for (int64_t i = e4 + threadIdx.x; i < b1; i += kStatsBlock) acc_minmax<ABS>(x[i], lo, hi);
+    for (int64_t i = e4 + threadIdx.x; i < b1; i += kStatsBlock) acc_minmax<ABS>(x[i], lo, hi, nan);
   } else {
-    for (int64_t i = b0 + threadIdx.x; i < b1; i += kStatsBlock) acc_minmax<ABS>(x[i], lo, hi);
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += kStatsBlock) acc_minmax<ABS>(x[i], lo, hi, nan);
   }
-  lo = wave_min(lo); hi = wave_max(hi);
+  poison(nan, lo, hi);
+  lo = wave_min_nan(lo); hi = wave_max_nan(hi);
   __shared__ float s_lo[kStatsBlock / 64], s_hi[kStatsBlock / 64];
   if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int t = 1; t < kStatsBlock / 64; ++t) { lo = fminf(lo, s_lo[t]); hi = fmaxf(hi, s_hi[t]); }
+    for (int t = 1; t < kStatsBlock / 64; ++t) { lo = nan_min(lo, s_lo[t]); hi = nan_max(hi, s_hi[t]); }
     pmin[blockIdx.x] = lo; pmax[blockIdx.x] = hi;
   }
 }
@@ -164,26 +176,26 @@ __global__ __launch_bounds__(256) void stats_merge_kernel(const float* __restric
   if (any && c < chan) {
     int64_t sl = w;
     for (; sl + 4 < S; sl += 8) {
-      lo0 = fminf(lo0, pmin[sl * chan + c]); hi0 = fmaxf(hi0, pmax[sl * chan + c]);
-      lo1 = fminf(lo1, pmin[(sl + 4) * chan + c]); hi1 = fmaxf(hi1, pmax[(sl + 4) * chan + c]);
+      lo0 = nan_min(lo0, pmin[sl * chan + c]); hi0 = nan_max(hi0, pmax[sl * chan + c]);
+      lo1 = nan_min(lo1, pmin[(sl + 4) * chan + c]); hi1 = nan_max(hi1, pmax[(sl + 4) * chan + c]);
     }
-    for (; sl < S; sl += 4) { lo0 = fminf(lo0, pmin[sl * chan + c]); hi0 = fmaxf(hi0, pmax[sl * chan + c]); }
+    for (; sl < S; sl += 4) { lo0 = nan_min(lo0, pmin[sl * chan + c]); hi0 = nan_max(hi0, pmax[sl * chan + c]); }
   }
-  s_lo[w][cl] = fminf(lo0, lo1); s_hi[w][cl] = fmaxf(hi0, hi1);
+  s_lo[w][cl] = nan_min(lo0, lo1); s_hi[w][cl] = nan_max(hi0, hi1);
   __syncthreads();
   if (w != 0 || c >= chan) return;
-  float lo = fminf(fminf(s_lo[0][cl], s_lo[1][cl]), fminf(s_lo[2][cl], s_lo[3][cl]));
-  float hi = fmaxf(fmaxf(s_hi[0][cl], s_hi[1][cl]), fmaxf(s_hi[2][cl], s_hi[3][cl]));
+  float lo = nan_min(nan_min(s_lo[0][cl], s_lo[1][cl]), nan_min(s_lo[2][cl], s_lo[3][cl]));
+  float hi = nan_max(nan_max(s_hi[0][cl], s_hi[1][cl]), nan_max(s_hi[2][cl], s_hi[3][cl]));
   if (!any) {
     if (first) { min_io[c] = log_eps_fill; max_io[c] = log_eps_fill; }  // :194-197
     return;                                                             // later batch: untouched
   }
   if (log_domain) {                                                     // :182-183
-    lo = log2_rn(fmaxf(lo, eps));
-    hi = log2_rn(fmaxf(hi, eps));
+    lo = log2_rn(nan_max(lo, eps));                                     // torch.clamp(min=eps) keeps NaN
+    hi = log2_rn(nan_max(hi, eps));
   }
   if (first) { min_io[c] = lo; max_io[c] = hi; }                        // :188-190 / :202-204
-  else { min_io[c] = fminf(min_io[c], lo); max_io[c] = fmaxf(max_io[c], hi); }  // :192-193 / :206-207
+  else { min_io[c] = nan_min(min_io[c], lo); max_io[c] = nan_max(max_io[c], hi); }  // :192-193 / :206-207 (torch.minimum/maximum)
 }
 
 // SwitchableLayerNorm.forward (switchable_batchnorm.py:102-109).  One wave per row; the row lives in registers (NV float4 per
@@ -269,11 +281,11 @@ __global__ void finish_scale_kernel(const float* __restrict__ rmin, const float*
     scale[i] = hi - lo;
     zp[i] = lo;
   } else if (symmetric) {                       // :119-123
-    float amax = fmaxf(fmaxf(fabsf(lo), fabsf(hi)), eps);
+    float amax = nan_max(nan_max(fabsf(lo), fabsf(hi)), eps);       // torch.max / torch.clamp keep NaN
     scale[i] = amax / (float)((1 << (bits - 1)) - 1);
     zp[i] = 0.f;
   } else {                                      // :124-127
-    float rng = fmaxf(hi - lo, eps);
+    float rng = nan_max(hi - lo, eps);
     float s = rng / (float)((1u << bits) - 1u);
     scale[i] = s;
     zp[i] = rintf(-lo / s);

@@ -26,6 +26,29 @@ import torch.nn.functional as F
 
 LOG_FN_EPS = 1e-5  # quantization_methods.py:35 -- hard-coded, independent of the module's eps
 
+# The two transcendental ops of the log path.  Default: exactly what the reference calls (ATen's CPU kernels, <= 1 ulp SLEEF
+# routines).  `correctly_rounded_transcendentals()` swaps in fp64-computed, fp32-rounded twins so that tools/log_tolerance_study.py
+# can measure how much of a log-path difference is the reference's own last-bit noise (test infrastructure; nothing else uses it).
+_log2 = torch.log2
+
+
+def _pow2(t):
+    return torch.pow(2, t)
+
+
+class correctly_rounded_transcendentals:
+    def __enter__(self):
+        global _log2, _pow2
+        self._saved = (_log2, _pow2)
+        _log2 = lambda t: torch.log2(t.double()).float()            # noqa: E731
+        _pow2 = lambda t: torch.pow(2.0, t.double()).float()        # noqa: E731
+        return self
+
+    def __exit__(self, *exc):
+        global _log2, _pow2
+        _log2, _pow2 = self._saved
+        return False
+
 
 # --------------------------------------------------------------------------------------------------
 # a1: MinMaxQuantizationFunction.forward            quantization_methods.py:8-22
@@ -62,7 +85,7 @@ def log_levels(x, log_min, log_range, bits: int, symmetric: bool = True
     Follows :41-61.  The pre-round value is returned so tests can classify a mismatch as tie-adjacent.
     """
     mag = torch.abs(x).clamp(min=LOG_FN_EPS)                                   # :45
-    lg = torch.log2(mag)                                                       # :47
+    lg = _log2(mag)                                                            # :47  torch.log2
     ln = (lg - log_min) / (log_range.clamp(min=LOG_FN_EPS))                    # :49
     ln = torch.clamp(ln, 0, 1)                                                 # :50
     if symmetric:
@@ -90,7 +113,7 @@ def log_fakequant(x, log_min, log_range, bits: int, symmetric: bool = True) -> t
         n = 2 ** bits - 1
         qn = q / n                                                             # :66
     x_hat = qn * log_range + log_min                                           # :68
-    out = torch.pow(2, x_hat) * sgn                                            # :70-72
+    out = _pow2(x_hat) * sgn                                                   # :70-72  torch.pow(2, x_hat)
     return torch.where(zero_mask, torch.zeros_like(x), out)                    # :74
 
 
@@ -142,7 +165,7 @@ class QuantState:
         if self.qtype == "log":
             ax = torch.abs(x)
             if (ax > self.eps).any():                                          # :179-181
-                lg = torch.log2(torch.clamp(ax, min=self.eps))                 # :182-183
+                lg = _log2(torch.clamp(ax, min=self.eps))                      # :182-183  torch.log2
                 lo, hi = keepdim_min_max(lg, _reduce_dims(lg.dim(), self.per_channel, cd))
                 self._merge(lo, hi)
             elif self.nbatches == 0:                                           # :194-197

@@ -52,7 +52,8 @@ def _worker(rank, world, port, ret):
                 oq.observe(b)
             q.temp_min, q.temp_max, q.num_batches_collected = oq.tmin.clone(), oq.tmax.clone(), len(mine)
         n = pkg.allreduce_calibration_stats(model)
-        assert len(calls) == 1 and calls[0] == n == 2 * (K + 1 + K), (calls, n)
+        # [agreement check: 2 floats per collecting quantizer] + [the ONE data collective]
+        assert calls == [2 * 3, n] and n == 2 * (K + 1 + K), (calls, n)
         # expected: one process over the union of all ranks' batches
         for q in (q1, q2, q4):
             oq = O.QuantState(q.num_bits, q.quantizer_type, -1, q.per_channel)
@@ -64,7 +65,21 @@ def _worker(rank, world, port, ret):
         assert q3.temp_min is None
         # nothing collecting any more -> no collective
         q1.collecting_stats = q2.collecting_stats = q4.collecting_stats = False
-        assert pkg.allreduce_calibration_stats(model) == 0 and len(calls) == 1
+        assert pkg.allreduce_calibration_stats(model) == 0 and len(calls) == 2
+        # a rank whose loader ran dry (no statistics for a collecting quantizer): every rank raises, nobody hangs
+        q5 = pkg.LearnableFakeQuantize(4, channel_dim=-1, quantizer_type="minmax", is_input=True)
+        q5.start_calibration()
+        if rank == 0:
+            q5.temp_min, q5.temp_max, q5.num_batches_collected = torch.zeros(1, 1, K), torch.ones(1, 1, K), 1
+        try:
+            pkg.allreduce_calibration_stats([q5])
+            raise AssertionError("missing statistics on one rank were not detected")
+        except RuntimeError as e:
+            assert "differ in size across ranks" in str(e), str(e)
+        # nobody saw a batch: no data collective, the quantizer stays as it is
+        q6 = pkg.LearnableFakeQuantize(4, channel_dim=-1, quantizer_type="minmax", is_input=True)
+        q6.start_calibration()
+        assert pkg.allreduce_calibration_stats([q6]) == 0 and q6.temp_min is None
         ret[rank] = "ok"
     except Exception as e:  # pragma: no cover
         ret[rank] = f"{type(e).__name__}: {e}"
