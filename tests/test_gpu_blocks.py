@@ -62,7 +62,7 @@ def test_spmlp_with_fused_gelu(pkg, name):
     meta, t = load_blk(name)
     m, key = build_mlp(pkg, meta, t)
     qt = meta["qtype"]
-    tol = 1e-5 if qt == "minmax" else 2e-5
+    tol = 1e-5
     for lin, tag in ((m.c_fc, "fc"), (m.c_proj, "proj")):          # chained calibration (c_proj sees gelu(c_fc)) as the reference's
         got, ref = lin.quantizers_input[key].scale.cpu(), t[f"{tag}.qx.scale"]
         if qt == "minmax" and tag == "fc":
@@ -100,7 +100,7 @@ def test_spmlp_with_fused_gelu(pkg, name):
     xg = x2.clone().requires_grad_(True)
     yg = m(xg)
     assert yg.grad_fn is not None and not m.c_fc._activation_fused
-    assert_close_y(yg, y.cpu(), f"{name}.train vs eval", 2e-5)
+    assert_close_y(yg, y.cpu(), f"{name}.train vs eval", 1e-5)
 
 
 @pytest.mark.parametrize("name", ["block_mm4", "block_mm8"])
@@ -138,12 +138,12 @@ def test_spblock_against_reference_fixture(pkg, name):
     # row by a quantisation step; all other rows meet the bound
     yd, yr = y.cpu().double(), t["y"].double()
     rms = float(yr.pow(2).mean().sqrt())
-    bad_rows = ((yd - yr).abs() > 2e-5 * yr.abs() + 2e-5 * rms).any(dim=-1)
+    bad_rows = ((yd - yr).abs() > 1e-5 * yr.abs() + 1e-5 * rms).any(dim=-1)
     assert float(bad_rows.float().mean()) <= 0.05, f"{name}: {int(bad_rows.sum())} of {bad_rows.numel()} token rows off"
     assert float((yd - yr).abs().max()) < 0.05 * rms
     # the reference's explicit attention formula instead of torch's fused kernel: same result to fp32 rounding
     blk.attn.use_sdpa = False
     with torch.no_grad():
         y_explicit = blk(x2)
-    same = ((y_explicit - y).abs() <= 2e-5 * y.abs() + 2e-5 * rms).all(dim=-1)
+    same = ((y_explicit - y).abs() <= 1e-5 * y.abs() + 1e-5 * rms).all(dim=-1)
     assert float((~same).float().mean()) <= 0.05

@@ -60,7 +60,7 @@ def test_spmodel_stack_against_reference_fixture(pkg, bits):
     model = model.to(DEV).eval()
     ids = t["ids"].to(DEV)
     calib = [t[f"calib{i}"].to(DEV) for i in range(meta["n_calib"])]
-    tol = 1e-5 if bits == 4 else 2e-5
+    tol = 1e-5
 
     model.set_precision(32)
     with torch.no_grad():
@@ -122,7 +122,7 @@ def test_reference_checkpoint_loads_and_runs(pkg, bits):
     assert list(sd.keys()) == list(ck["model_state_dict"].keys())
     assert all(sd[k].shape == v.shape for k, v in ck["model_state_dict"].items())
     ids = exp["ids"].to(DEV)
-    tol = 1e-5 if bits == 4 else 2e-5
+    tol = 1e-5
     with torch.no_grad():
         hidden = model.transformer(ids)
         logits = model(ids)

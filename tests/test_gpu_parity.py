@@ -167,7 +167,7 @@ def test_layer_case(pkg, name, path):
     if path == "u8x2":
         want = pkg._lib.PATH_U8X2 if meta["bits"] <= 8 else (pkg._lib.PATH_F16X2 if meta["bits"] <= 12 else pkg._lib.PATH_F32)
     assert layer._last_path == want, (layer._last_path, want)
-    tol = 1e-5 if qt == "minmax" else 2e-5   # log: +1 ulp on ~2% of dequantised operands, see DESIGN.md
+    tol = 1e-5   # minmax and log alike (tools/log_tolerance_study.py: the log fixtures sit at <= 0.15 of this bound)
     assert_close_y(y2, t["y_x2"], f"{name}.y_x2", tol)
     assert_close_y(y0, t["y_x0"], f"{name}.y_x0", tol)
     assert_close_y(base, t["base_x2"], f"{name}.base_x2", tol)
@@ -286,21 +286,21 @@ def test_backward_against_reference_autograd(pkg, name):
     xg = t["xg"].to(DEV).requires_grad_(True)
     y = layer(xg)
     assert y.grad_fn is not None and "SPLinearFunction" in type(y.grad_fn).__name__
-    tol = 1e-5 if meta["qtype"] == "minmax" else 2e-5
+    tol = 1e-5
     assert_close_y(y, t["y"], f"{name}.y", tol)
     y.backward(t["g"].to(DEV))
     lo = layer.lora_adapters[key]
-    assert_close_y(xg.grad, t["grad_x"], f"{name}.grad_x", 2e-5)
-    assert_close_y(lo.lora_A.grad, t["grad_A"], f"{name}.grad_A", 2e-5)
-    assert_close_y(lo.lora_B.grad, t["grad_B"], f"{name}.grad_B", 2e-5)
+    assert_close_y(xg.grad, t["grad_x"], f"{name}.grad_x", 1e-5)
+    assert_close_y(lo.lora_A.grad, t["grad_A"], f"{name}.grad_A", 1e-5)
+    assert_close_y(lo.lora_B.grad, t["grad_B"], f"{name}.grad_B", 1e-5)
     assert layer.linear.weight.grad is None
     # same gradients from the fp32-MFMA contraction (backward_limbs = False)
     layer.backward_limbs = False
     lo.lora_A.grad = None; lo.lora_B.grad = None
     xg1 = t["xg"].to(DEV).requires_grad_(True)
     layer(xg1).backward(t["g"].to(DEV))
-    assert_close_y(xg1.grad, t["grad_x"], f"{name}.grad_x(f32)", 2e-5)
-    assert_close_y(lo.lora_A.grad, t["grad_A"], f"{name}.grad_A(f32)", 2e-5)
+    assert_close_y(xg1.grad, t["grad_x"], f"{name}.grad_x(f32)", 1e-5)
+    assert_close_y(lo.lora_A.grad, t["grad_A"], f"{name}.grad_A(f32)", 1e-5)
     layer.backward_limbs = True
     # trainable base weight + bias: straight-through d/dW = g^T . FQ(x), d/db = sum g
     layer.linear.weight.requires_grad_(True); layer.linear.bias.requires_grad_(True)

@@ -82,7 +82,7 @@ def test_linear_shapes_against_oracle(pkg, name, M, K, N, r, bits, qtype, pc):
         layer.calibration_mode = True
         base = layer(x1.to(DEV))
         layer.calibration_mode = False
-    tol = 1e-5 if qtype == "minmax" else 2e-5
+    tol = 1e-5
     assert_close_y(y, ol.forward(x1), f"{name}.y", tol)
     assert_close_y(base, ol.forward(x1, calibration_mode=True), f"{name}.base", tol)
     want = pkg._lib.PATH_F16X2 if (qtype == "minmax" and bits <= 12) else pkg._lib.PATH_F16X3
@@ -99,7 +99,7 @@ def test_asymmetric_quantizers(pkg, qtype, bits, pc):
     """quantization.py:17-20 / :50-54 asymmetric branches (the reference's layers never enable them, its quantizer class
     does): activations go as two fp16 limbs of FQ(x); the fp32 operands agree."""
     layer, ol, x0, x1 = make_pair(pkg, 640, 192, 320, 24, bits, qtype, pc, seed=5, symmetric=False)
-    tol = 1e-5 if qtype == "minmax" else 2e-5
+    tol = 1e-5
     with torch.no_grad():
         y = layer(x1.to(DEV))
         assert layer._last_path == pkg._lib.PATH_F16X3
