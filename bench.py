@@ -167,7 +167,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--path", choices=["auto", "f32", "f16x2", "u8x2", "f16x3"], default="auto")
+    ap.add_argument("--path", choices=["auto", "f32", "f16x2", "u8x2", "f16x3", "i8"], default="auto")
     ap.add_argument("--hoist-weights", action="store_true",
                     help="reuse prepared weight operands across steps (eval-mode behaviour of the module)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -216,7 +216,8 @@ def main():
         layer.lora_adapters[key].lora_A.copy_(A); layer.lora_adapters[key].lora_B.copy_(B)
     layer = layer.to(dev).eval()
     layer.set_precision(BITS)
-    layer.operand_path = {"auto": pkg._lib.PATH_AUTO, "f32": pkg._lib.PATH_F32, "f16x2": pkg._lib.PATH_F16X2, "u8x2": pkg._lib.PATH_U8X2, "f16x3": pkg._lib.PATH_F16X3}[args.path]
+    layer.operand_path = {"auto": pkg._lib.PATH_AUTO, "f32": pkg._lib.PATH_F32, "f16x2": pkg._lib.PATH_F16X2, "u8x2": pkg._lib.PATH_U8X2,
+                          "f16x3": pkg._lib.PATH_F16X3, "i8": pkg._lib.PATH_I8}[args.path]
     layer.cache_operands = bool(args.hoist_weights)
 
     # calibration: 2 local batches per rank, then ONE all-reduce(MAX) of [-min | max] (RCCL) -> identical scales
@@ -338,30 +339,36 @@ def main():
         value = world * FLOP_PER_STEP * args.steps / elapsed / 1e9
         gemm_avg_ms = sum(gemm_ms) / max(1, len(gemm_ms))
         is_f16 = path_used in (pkg._lib.PATH_F16X2, pkg._lib.PATH_U8X2, pkg._lib.PATH_F16X3)
+        is_i8 = path_used == pkg._lib.PATH_I8
         achieved = FLOP_PER_STEP / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms > 0 else 0.0
-        peak = PEAK["f16"] if is_f16 else PEAK["f32"]
+        peak = PEAK["i8"] if is_i8 else (PEAK["f16"] if is_f16 else PEAK["f32"])
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                rec = json.load(open(tpath)).get("f16x2" if is_f16 else "f32", {})
+                rec = json.load(open(tpath)).get("i8" if is_i8 else ("f16x2" if is_f16 else "f32"), {})
                 traffic = rec.get("hbm_bytes_per_launch")
                 traffic_source = (f"profiles/pmc_traffic.json ({rec.get('kernel', '?')}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                   f"passes of {rec.get('measured', 'an earlier run')}, not this run)")
             except Exception:
                 traffic = None
-        kernel_name = ("gemm_f16x2_t128 / gemm_f16x2_s16 (dense contraction + LoRA-up + bias, v_mfma_f32_16x16x32_f16)" if is_f16
+        kernel_name = ("gemm_i8_k128_kernel (dense contraction on v_mfma_i32_32x32x32_i8 + LoRA-up on f16 limbs + bias)" if is_i8 else
+                       "gemm_f16x2_t128 / gemm_f16x2_s16 (dense contraction + LoRA-up + bias, v_mfma_f32_16x16x32_f16)" if is_f16
                        else "gemm_f32_nt (dense contraction + LoRA-up + bias)")
+        dtype_s = ("i8 (int8 levels x int8 weight levels, i32 accumulate: exact)" if is_i8 else
+                   "f16x2-limb operands, f32 accumulate (fp32-accurate)" if is_f16 else "f32")
+        peak_s = ("i8 dense MFMA (2x the f16 rate; one product per algorithmic product)" if is_i8 else
+                  "f16 dense MFMA (2 limb products per algorithmic product)" if is_f16 else "f32-input MFMA")
         out = {
             "metric": "fused quant-GEMM-LoRA fwd GFLOP/s per GPU, GPT-2 c_fc 768→3072 @ 4-bit",
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "setup_steps": SETUP_STEPS, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16x2-limb operands, f32 accumulate (fp32-accurate)" if is_f16 else "f32",
+            "dtype": dtype_s,
             "data": "synthetic",
             "config": {"workload": "SPLinearWithLoRA c_fc 768->3072, 4-bit minmax per-channel + LoRA r=64, "
                                    "batch 8 x seq 1024 = 8192 tokens per GPU (SURVEY.md 8d headline)",
                        "tokens_per_gpu": M_TOKENS, "parallelism": f"dp{world} (replicas over the batch)",
-                       "operand_path": {1: "f32", 2: "f16x2", 3: "u8x2", 4: "f16x3"}.get(path_used, str(path_used)),
+                       "operand_path": pkg._lib.PATH_NAMES.get(path_used, str(path_used)),
                        "weights_requantized_every_step": not args.hoist_weights,
                        "flop_per_step_per_gpu": FLOP_PER_STEP, "algorithmic_bytes_per_step_per_gpu": BYTES_PER_STEP},
             "value_per_gpu": round(value / world, 1),
@@ -383,8 +390,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kernel_name,
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel_launches_timed": len(gemm_ms), "peak_dtype": "f16 dense MFMA (2 limb products per algorithmic product)" if is_f16
-                         else "f32-input MFMA", "kernel_ms_avg": round(gemm_avg_ms, 4),
+                         "kernel_launches_timed": len(gemm_ms), "peak_dtype": peak_s, "kernel_ms_avg": round(gemm_avg_ms, 4),
+                         "frac_vs_f16_mfma_peak": round(achieved / PEAK["f16"], 4),
                          "kernel_ms_min": round(min(gemm_ms), 4) if gemm_ms else None,
                          "frac_vs_f32_mfma_peak": round(achieved / PEAK["f32"], 4)},
         }

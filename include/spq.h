@@ -49,9 +49,13 @@ enum spq_path {
   SPQ_PATH_F32 = 1,   /* fp32-input MFMA on dequantised fp32 operands: always valid */
   SPQ_PATH_F16X2 = 2, /* exact integer levels (fp16) x 2-limb fp16 weights on f16 MFMA: minmax, symmetric, bits<=12 */
   SPQ_PATH_U8X2 = 3,  /* same arithmetic, levels stored as bytes (bits<=8), 3-slot LDS ring; same prepared operands as F16X2 */
-  SPQ_PATH_F16X3 = 4  /* any input quantizer (log, asymmetric, >12 bit) or none at all (quantize_input = 0: plain fp32
+  SPQ_PATH_F16X3 = 4, /* any input quantizer (log, asymmetric, >12 bit) or none at all (quantize_input = 0: plain fp32
                          activations, e.g. a gradient): FQ(x)*2^G as two fp16 limbs x 2-limb weights, three f16 MFMA
                          products per algorithmic product; operands prepared with sx = 1 (no scale folding) */
+  SPQ_PATH_I8 = 5     /* int8 matrix cores (2x the f16 rate), ONE product per algorithmic product: symmetric minmax input
+                         quantizer of <= 8 bits with a PER-TENSOR scale (it then leaves the sum) and symmetric minmax weights
+                         of <= 8 bits: y = (sw[n] * sx) * sum_k q[m,k] wq[n,k], the integer sum exact in i32; LoRA-up stays on
+                         fp16 limbs.  (The reference's evaluation loader forces per-tensor scales: deploy.py:210,238.) */
 };
 
 enum spq_epilogue { SPQ_EPILOGUE_NONE = 0, SPQ_EPILOGUE_GELU = 1 };
@@ -168,6 +172,20 @@ int spq_gemm_f32_nt(const float* A, int64_t lda, const float* B, int64_t ldb, in
  *   y = FQ_x(x) . FQ_w(W)^T + bias + scaling * (x . FQ_A(A)) . FQ_B(B)        (LoRA on the RAW x)
  * from operands prepared once per (weights, scales) by spq_prepare_* below.
  * ------------------------------------------------------------------------------------------------- */
+/* The arguments of spq_prepare_f16x2 (below) as a struct: spq_prepare_f16x2_args(&p, stream) is the same call, and a pointer
+ * to one in spq_fwd_args.prepare makes the forward (re)build the weight-side operands itself -- what the reference does on
+ * every call (lora.py:142 FQ(W), :49-50 FQ(A), FQ(B)) -- without a launch of their own where the shapes allow it. */
+typedef struct spq_prepare_args {
+  const float* W; int64_t N, K; const float* sw; const float* zw; int w_per_channel, w_bits, w_qtype, w_symmetric;
+  const float* B; int64_t r; const float* sb; const float* zb; int b_per_channel, b_bits, b_qtype, b_symmetric;
+  float scaling;
+  const float* A; const float* sa; const float* za; int a_per_channel, a_bits, a_qtype, a_symmetric;
+  const float* sx; int x_per_channel;
+  void* w_prep; size_t w_prep_bytes; float* w_rowscale; float* a_prep;
+  int path;  /* 0 / SPQ_PATH_F16X2 / U8X2 / F16X3: two fp16 limb planes (w_prep of spq_prep_f16x2_bytes());
+                SPQ_PATH_I8: the int8 plane of weight levels (w_prep of spq_prep_bytes(N, K, r, path)) */
+} spq_prepare_args;
+
 typedef struct spq_fwd_args {
   /* problem */
   int64_t M, K, N, r;          /* r = 0: no LoRA branch (calibration_mode or disabled adapter) */
@@ -213,6 +231,11 @@ typedef struct spq_fwd_args {
    * pass then runs on the f16 matrix pipe (two fp16 limbs of x * 2^g[m] per 32-row panel and of a_prep * 2^S) instead of
    * the fp32-input MFMA.  NULL: fp32-input MFMA. */
   const float* a_limb_scale;
+  /* F16 operand paths, optional: (re)make w_prep / w_rowscale / a_prep / b_prep from the fp32 weights as part of this call
+   * (its buffers must be the ones named above).  In the activation stage only.  The row work is spread over the activation
+   * pass's workgroups when that pass is the 16-row kernel (M < 16384) and each workgroup gets <= 8 rows; otherwise the
+   * ordinary preparation launch is issued first.  SPQ_FUSE_PREPARE=0 always takes the latter. */
+  const struct spq_prepare_args* prepare;
 } spq_fwd_args;
 
 size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path);
@@ -229,6 +252,8 @@ int spq_linear_lora_fwd(const spq_fwd_args* args, spq_stream_t stream);
  * w_prep: spq_prep_f16x2_bytes() bytes, 16-B aligned.  w_rowscale: ceil(N/128)*128 floats (2^-e[n]).
  * ------------------------------------------------------------------------------------------------- */
 size_t spq_prep_f16x2_bytes(int64_t N, int64_t K, int64_t r);
+size_t spq_prep_bytes(int64_t N, int64_t K, int64_t r, int path);   /* per operand path (an int8 plane for SPQ_PATH_I8) */
+int spq_prepare_f16x2_args(const spq_prepare_args* args, spq_stream_t stream);
 int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const float* sw, const float* zw,
                       int w_per_channel, int w_bits, int w_qtype, int w_symmetric, const float* B, int64_t r,
                       const float* sb, const float* zb, int b_per_channel, int b_bits, int b_qtype,

@@ -16,7 +16,8 @@ STAGE_ALL, STAGE_ACTIVATIONS, STAGE_CONTRACTION = 0, 1, 2
 EPILOGUE_NONE, EPILOGUE_GELU = 0, 1
 COMM_ID_BYTES = 128
 LIMB_SCALE_WORKSPACE_BYTES = 16384
-PATH_AUTO, PATH_F32, PATH_F16X2, PATH_U8X2, PATH_F16X3 = 0, 1, 2, 3, 4
+PATH_AUTO, PATH_F32, PATH_F16X2, PATH_U8X2, PATH_F16X3, PATH_I8 = 0, 1, 2, 3, 4, 5
+PATH_NAMES = {1: "f32", 2: "f16x2", 3: "u8x2", 4: "f16x3", 5: "i8"}
 LOG_DIRECT = 2
 QTYPE_CODE = {"minmax": MINMAX, "log": LOG}            # part1 quantizers
 QTYPE_CODE_CPT = {"minmax": MINMAX, "log": LOG_DIRECT}  # part2 quantizers (log without the level round trip)
@@ -30,6 +31,18 @@ _f = C.c_float
 _sz = C.c_size_t
 
 
+class PrepareArgs(C.Structure):
+    """struct spq_prepare_args (include/spq.h): the arguments of spq_prepare_f16x2."""
+    _fields_ = [("W", _p), ("N", _i64), ("K", _i64), ("sw", _p), ("zw", _p),
+                ("w_per_channel", _int), ("w_bits", _int), ("w_qtype", _int), ("w_symmetric", _int),
+                ("B", _p), ("r", _i64), ("sb", _p), ("zb", _p),
+                ("b_per_channel", _int), ("b_bits", _int), ("b_qtype", _int), ("b_symmetric", _int), ("scaling", _f),
+                ("A", _p), ("sa", _p), ("za", _p),
+                ("a_per_channel", _int), ("a_bits", _int), ("a_qtype", _int), ("a_symmetric", _int),
+                ("sx", _p), ("x_per_channel", _int),
+                ("w_prep", _p), ("w_prep_bytes", _sz), ("w_rowscale", _p), ("a_prep", _p), ("path", _int)]
+
+
 class FwdArgs(C.Structure):
     """struct spq_fwd_args (include/spq.h)."""
     _fields_ = [("M", _i64), ("K", _i64), ("N", _i64), ("r", _i64),
@@ -39,7 +52,8 @@ class FwdArgs(C.Structure):
                 ("w_prep", _p), ("w_rowscale", _p), ("bias", _p), ("a_prep", _p), ("b_prep", _p),
                 ("lora_scaling", _f),
                 ("y", _p), ("workspace", _p), ("workspace_bytes", _sz),
-                ("ev_gemm_begin", _p), ("ev_gemm_end", _p), ("t_out", _p), ("lora_on_fq_input", _int), ("stage", _int), ("epilogue", _int), ("a_limb_scale", _p)]
+                ("ev_gemm_begin", _p), ("ev_gemm_end", _p), ("t_out", _p), ("lora_on_fq_input", _int), ("stage", _int), ("epilogue", _int), ("a_limb_scale", _p),
+                ("prepare", C.POINTER(PrepareArgs))]
 
 
 # name -> (restype, argtypes); must list every symbol include/spq.h declares (tests/test_cabi.py checks).
@@ -66,6 +80,8 @@ SIGNATURES = {
     "spq_fwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _int]),
     "spq_linear_lora_fwd": (_int, [C.POINTER(FwdArgs), _p]),
     "spq_prep_f16x2_bytes": (_sz, [_i64, _i64, _i64]),
+    "spq_prep_bytes": (_sz, [_i64, _i64, _i64, _int]),
+    "spq_prepare_f16x2_args": (_int, [C.POINTER(PrepareArgs), _p]),
     "spq_prepare_f16x2": (_int, [_p, _i64, _i64, _p, _p, _int, _int, _int, _int,          # W
                                  _p, _i64, _p, _p, _int, _int, _int, _int, _f,            # B
                                  _p, _p, _p, _int, _int, _int, _int,                      # A

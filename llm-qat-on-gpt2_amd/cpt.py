@@ -349,7 +349,8 @@ class _QuantGemm:
                 if use_lora:
                     aq, bq = ql(lo.lora_A.detach()), ql(lo.lora_B.detach())
                     self.aq.copy_(aq); self.bq.copy_(bq)
-                    torch.addmm(wq, bq, aq.t(), alpha=float(lo.scaling), out=self.w_eff)
+                    # W_eff = FQ(W) + s * FQ(B) . FQ(A)^T: the rank-r product on this library's fp32-MFMA kernel (no vendor BLAS)
+                    torch.add(wq, _gemm_nt(bq.contiguous(), aq.contiguous()), alpha=float(lo.scaling), out=self.w_eff)
                     if want_aq_t:
                         self.aq_t.zero_()
                         self.aq_t[:r].copy_(aq.t())
@@ -584,7 +585,7 @@ class _CPTLinearFunction(torch.autograd.Function):
             if use_lora and need_B:
                 gB = _ste(quantize_gradient(_gemm_tn(g2, t, s), lo.grad_quantizer_B), ql)
             if need_W:
-                gW = _ste(g2.t() @ xq, qw)
+                gW = _ste(_gemm_tn(g2, xq.contiguous()), qw)           # g^T . FQ(x) on spq_gemm_f32_tn
             if need_b:
                 gb = g2.sum(dim=0)
         return gx, gW, gb, gA, gB, None, None

@@ -60,7 +60,8 @@ extern "C" int spq_device_arch(char* buf, int buflen) {
 
 extern "C" size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path) {
   if (M <= 0 || K <= 0 || N <= 0 || r < 0) return 0;
-  if (path == SPQ_PATH_F16X2 || path == SPQ_PATH_U8X2 || path == SPQ_PATH_F16X3) return fwd_f16x2_workspace_bytes(M, K, N, r);
+  if (path == SPQ_PATH_F16X2 || path == SPQ_PATH_U8X2 || path == SPQ_PATH_F16X3 || path == SPQ_PATH_I8)
+    return fwd_f16x2_workspace_bytes(M, K, N, r);
   // F32 path: fake-quantised activations [M,K] + low-rank intermediate [M,r]
   return align_up((size_t)M * K * sizeof(float), 256) + align_up((size_t)M * (size_t)r * sizeof(float), 256) + 256;
 }
@@ -80,7 +81,8 @@ extern "C" int spq_linear_lora_fwd(const spq_fwd_args* a, spq_stream_t stream) {
               spq_fwd_workspace_bytes(a->M, a->K, a->N, a->r, a->path));
     return SPQ_ERR_WORKSPACE;
   }
-  if (a->path == SPQ_PATH_F16X2 || a->path == SPQ_PATH_U8X2 || a->path == SPQ_PATH_F16X3) return fwd_f16x2(a, st);
+  if (a->path == SPQ_PATH_F16X2 || a->path == SPQ_PATH_U8X2 || a->path == SPQ_PATH_F16X3 || a->path == SPQ_PATH_I8)
+    return fwd_f16x2(a, st);
   if (a->path != SPQ_PATH_F32) {
     set_error("spq_linear_lora_fwd: unknown operand path %d", a->path);
     return SPQ_ERR_UNSUPPORTED;

@@ -19,9 +19,11 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "spq_common.h"
+#include "spq_i8_kernel.h"
 
 namespace spq {
 
@@ -89,6 +91,9 @@ struct PrepArgs {
   const float* A; const float* sa; const float* za; float* aT;
   int a_pc, a_bits, a_qtype, a_sym;
   int row_blocks;
+  // SPQ_PATH_I8 (nl = 1, else 0): the int8 plane of weight levels [Np, Kp]; the LoRA-B limbs then carry a row exponent of
+  // their own, bscale[n] = 2^-eb[n]
+  signed char* W8; int64_t plane_stride; float* bscale; int nl;
 };
 
 template <int QT, bool SYM>
@@ -219,7 +224,7 @@ struct XPassArgs {
   _Float16 *qx, *thi, *tlo; float* rowinv;
   int M, K, r, Kp, Rp;
   int x_pc, bits;
-  int a8;                                   // 1: levels are written as bytes q + 128 (bits <= 8), else as fp16
+  int a8;                                   // 1: levels are written as bytes q + 128 (bits <= 8), 2: as int8 q, else as fp16
   // limbs != 0 (SPQ_PATH_F16X3): any input quantizer; FQ(x) * xscale[0] is written as two fp16 limbs (qx = hi, xl = lo)
   int limbs, qtype, symmetric;
   _Float16* xl;
@@ -233,10 +238,74 @@ struct XPassArgs {
 // the limb pass, reductions are 64-lane shuffles, loads are 16 B per lane and stores 8 B per lane.  Needs K % 4 == 0,
 // K <= 4096, 16-B aligned W / sx.
 constexpr int PREP_MAXI = 16;
-__global__ __launch_bounds__(256) void prep_f16x2_wave_kernel(PrepArgs a) {
-  if ((int)blockIdx.x >= a.row_blocks) { fq_transpose_tile(a, blockIdx.x - a.row_blocks); return; }
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+// SPQ_PATH_I8: one output row of the int8 weight operand -- the weight's own integer levels (symmetric minmax, <= 8 bit) --
+// by ONE wave; rowscale[n] = sw[n] * sx (per-tensor input scale); the LoRA-B limbs get a row exponent of their own (bscale).
+template <int MAXI>
+__device__ __forceinline__ void prep_row_wave_i8(const PrepArgs& a, int n, int lane, const float* sb_row) {
+  signed char* w8 = a.W8 + (int64_t)n * a.Kp;
+  _Float16* bhi = a.Bhi ? a.Bhi + (int64_t)n * a.Rp : nullptr;
+  _Float16* blo = a.Blo ? a.Blo + (int64_t)n * a.Rp : nullptr;
+  const int kp4 = a.Kp >> 2, k4n = a.K >> 2;
+  if (n >= a.N) {                       // padding rows: zeros
+    for (int k4 = lane; k4 < kp4; k4 += 64) *reinterpret_cast<unsigned*>(w8 + 4 * k4) = 0u;
+    if (bhi) for (int j = lane; j < a.Rp; j += 64) { bhi[j] = (_Float16)0.f; blo[j] = (_Float16)0.f; }
+    if (lane == 0) { a.rowscale[n] = 1.f; if (a.bscale) a.bscale[n] = 1.f; }
+    return;
+  }
+  const float swn = a.sw[a.w_pc ? n : 0];
+  const float4* Wrow = reinterpret_cast<const float4*>(a.W + (int64_t)n * a.K);
+  const float qn = (float)((1 << (a.w_bits - 1)) - 1);
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int k4 = lane + 64 * i;
+    if (k4 < kp4) {
+      unsigned d = 0u;
+      if (k4 < k4n) {
+        const float4 v = Wrow[k4];      // integer levels (quantization_methods.py:14-15)
+        const int l0 = (int)minmax_level<true>(v.x, swn, 0.f, -qn, qn), l1 = (int)minmax_level<true>(v.y, swn, 0.f, -qn, qn);
+        const int l2 = (int)minmax_level<true>(v.z, swn, 0.f, -qn, qn), l3 = (int)minmax_level<true>(v.w, swn, 0.f, -qn, qn);
+        d = (unsigned)(l0 & 255) | ((unsigned)(l1 & 255) << 8) | ((unsigned)(l2 & 255) << 16) | ((unsigned)(l3 & 255) << 24);
+      }
+      *reinterpret_cast<unsigned*>(w8 + 4 * k4) = d;
+    }
+  }
+  if (lane == 0) a.rowscale[n] = swn * a.sx[0];          // the product of the two scales, one fp32 rounding
+  if (bhi) {
+    float bq[2] = {0.f, 0.f};
+    float bmax = 0.f;
+    if (a.B) {
+      const float sbn = a.sb[a.b_pc ? n : 0], zbn = a.zb[a.b_pc ? n : 0];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int j = lane + 64 * i;
+        if (j < a.r) {
+          const float braw = sb_row ? sb_row[j] : a.B[(int64_t)j * a.N + n];
+          bq[i] = fq_dispatch(braw, sbn, zbn, a.b_bits, a.b_qtype, a.b_sym) * a.scaling;
+          bmax = fmaxf(bmax, fabsf(bq[i]));
+        }
+      }
+    }
+    bmax = wave_max(bmax);
+    const float pb = pow2_scale_for(bmax);
+    if (lane == 0) a.bscale[n] = 1.0f / pb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = lane + 64 * i;
+      if (j < a.Rp) {
+        _Float16 hh = (_Float16)0.f, ll = (_Float16)0.f;
+        if (a.B && j < a.r) split2(bq[i] * pb, hh, ll);
+        bhi[j] = hh; blo[j] = ll;
+      }
+    }
+  }
+}
+
+// one output row n of the weight-side operands, by ONE wave (lane = threadIdx.x & 63).  `sb_row` (nullable): the row's raw
+// LoRA-B column B[0..r-1][n] staged contiguously by the caller (LDS) instead of the strided global read.
+// MODE 0: two fp16 limbs of W' * 2^e[n] (F16X2 / F16X3).  MODE 1: the weight's own integer levels as int8 (SPQ_PATH_I8).
+template <int MODE, int MAXI = PREP_MAXI>    // MAXI: float4 loads per lane that cover a row (K <= 256 * MAXI)
+__device__ __forceinline__ void prep_row_wave(const PrepArgs& a, int n, int lane, const float* sb_row) {
+  if constexpr (MODE != 0) { prep_row_wave_i8<MAXI>(a, n, lane, sb_row); return; }
   _Float16* whi = a.Whi + (int64_t)n * a.Kp;
   _Float16* wlo = a.Wlo + (int64_t)n * a.Kp;
   _Float16* bhi = a.Bhi ? a.Bhi + (int64_t)n * a.Rp : nullptr;
@@ -253,10 +322,10 @@ __global__ __launch_bounds__(256) void prep_f16x2_wave_kernel(PrepArgs a) {
   }
   const float swn = a.sw[a.w_pc ? n : 0], zwn = a.zw[a.w_pc ? n : 0];
   const float4* Wrow = reinterpret_cast<const float4*>(a.W + (int64_t)n * a.K);
-  float4 wq[PREP_MAXI];
+  float4 wq[MAXI];
   float vmax = 0.f;
 #pragma unroll
-  for (int i = 0; i < PREP_MAXI; ++i) {
+  for (int i = 0; i < MAXI; ++i) {
     const int k4 = lane + 64 * i;
     if (k4 < k4n) {
       const float4 v = Wrow[k4];
@@ -280,7 +349,8 @@ __global__ __launch_bounds__(256) void prep_f16x2_wave_kernel(PrepArgs a) {
     for (int i = 0; i < 2; ++i) {
       const int j = lane + 64 * i;
       if (j < a.r) {
-        bq[i] = fq_dispatch(a.B[(int64_t)j * a.N + n], sbn, zbn, a.b_bits, a.b_qtype, a.b_sym) * a.scaling;
+        const float braw = sb_row ? sb_row[j] : a.B[(int64_t)j * a.N + n];
+        bq[i] = fq_dispatch(braw, sbn, zbn, a.b_bits, a.b_qtype, a.b_sym) * a.scaling;
         vmax = fmaxf(vmax, fabsf(bq[i]));
       }
     }
@@ -289,7 +359,7 @@ __global__ __launch_bounds__(256) void prep_f16x2_wave_kernel(PrepArgs a) {
   const float p = pow2_scale_for(vmax);
   if (lane == 0) a.rowscale[n] = 1.0f / p;               // exact: p is a power of two
 #pragma unroll
-  for (int i = 0; i < PREP_MAXI; ++i) {
+  for (int i = 0; i < MAXI; ++i) {
     const int k4 = lane + 64 * i;
     if (k4 < kp4) {
       union { _Float16 h[4]; uint2 u; } hi, lo;
@@ -316,6 +386,26 @@ __global__ __launch_bounds__(256) void prep_f16x2_wave_kernel(PrepArgs a) {
     }
   }
 }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void prep_wave_kernel(PrepArgs a, int at_blocks) {
+  // the FQ(A)^T tiles come FIRST in the grid (they are the longer workgroups: a tail of them cost ~2 us)
+  if ((int)blockIdx.x < at_blocks) { fq_transpose_tile(a, blockIdx.x); return; }
+  const int n0 = ((int)blockIdx.x - at_blocks) * 4;
+  // the four rows' LoRA-B columns B[j][n0 .. n0+3] are 16-byte runs: one coalesced-per-j load by the workgroup, staged in LDS,
+  // instead of a strided scalar read per (row, j) from every wave
+  __shared__ float sB[4][128];
+  const bool staged = a.B && n0 + 3 < a.N && (a.N & 3) == 0;
+  if (staged) {
+    for (int e = threadIdx.x; e < a.r * 4; e += 256) sB[e & 3][e >> 2] = a.B[(int64_t)(e >> 2) * a.N + n0 + (e & 3)];
+    __syncthreads();
+  }
+  const int wv = threadIdx.x >> 6;
+  prep_row_wave<MODE>(a, n0 + wv, threadIdx.x & 63, staged ? &sB[wv][0] : nullptr);
+}
+
+// FQ(A)^T alone (the first of the two operand launches when the row work rides in the activation pass)
+__global__ __launch_bounds__(256) void fq_transpose_kernel(PrepArgs a) { fq_transpose_tile(a, blockIdx.x); }
 
 // Shared tail of the activation pass: sum the NW per-wave K-partials of t (fixed order), per-row power-of-two scale,
 // two fp16 limbs.  `red` must hold NW * XR * RP floats and be free of other use (caller synchronised).  All threads
@@ -404,8 +494,9 @@ __device__ __forceinline__ void store_act4(const XPassArgs& a, int64_t idx, floa
   const float q0 = minmax_level<true>(v.x, sc.x, 0.f, qlo, qhi), q1 = minmax_level<true>(v.y, sc.y, 0.f, qlo, qhi);
   const float q2 = minmax_level<true>(v.z, sc.z, 0.f, qlo, qhi), q3 = minmax_level<true>(v.w, sc.w, 0.f, qlo, qhi);
   if (a.a8) {
-    const unsigned u = (unsigned)((int)q0 + 128) | ((unsigned)((int)q1 + 128) << 8) | ((unsigned)((int)q2 + 128) << 16) |
-                       ((unsigned)((int)q3 + 128) << 24);
+    const int b8 = a.a8 == 1 ? 128 : 0;                  // 1: bytes q + 128 (SPQ_PATH_U8X2); 2: int8 q (SPQ_PATH_I8)
+    const unsigned u = (unsigned)(((int)q0 + b8) & 255) | ((unsigned)(((int)q1 + b8) & 255) << 8) |
+                       ((unsigned)(((int)q2 + b8) & 255) << 16) | ((unsigned)(((int)q3 + b8) & 255) << 24);
     *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(a.qx) + idx) = u;
   } else {
     union { _Float16 hh[4]; uint2 u; } q;
@@ -423,8 +514,9 @@ __device__ __forceinline__ float4 fq_act4(const XPassArgs& a, float4 v, float4 s
 // four consecutive integer levels -> level matrix at element index idx (fp16, or bytes q + 128 when a8)
 __device__ __forceinline__ void store_levels4(_Float16* qx, int64_t idx, float q0, float q1, float q2, float q3, int a8) {
   if (a8) {
-    const unsigned u = (unsigned)((int)q0 + 128) | ((unsigned)((int)q1 + 128) << 8) | ((unsigned)((int)q2 + 128) << 16) |
-                       ((unsigned)((int)q3 + 128) << 24);
+    const int b8 = a8 == 1 ? 128 : 0;
+    const unsigned u = (unsigned)(((int)q0 + b8) & 255) | ((unsigned)(((int)q1 + b8) & 255) << 8) |
+                       ((unsigned)(((int)q2 + b8) & 255) << 16) | ((unsigned)(((int)q3 + b8) & 255) << 24);
     *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(qx) + idx) = u;
   } else {
     union { _Float16 hh[4]; uint2 u; } q;
@@ -700,7 +792,11 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
 constexpr int XR16 = 16, XP16R_CH = 8;
 constexpr int XP16R_XS = XP16R_CH * XR16 * 256;             // 32 KB
 constexpr int XP16R_LDS = XP16R_XS + XP_NAS * XP_AS + 2 * XP16R_CH * 64 * 4;   // + 32 KB + 4 KB
-__global__ __launch_bounds__(256, 2) void xpass_rows16_kernel(XPassArgs a) {
+// PREP: every workgroup first makes `prep_rows` consecutive rows of the weight-side operands (prep_row_wave: FQ(W), fold sx,
+// FQ(B) column, exponent, limb split) -- the work of prep_f16x2_wave_kernel spread over the activation pass's workgroups, so
+// the per-call re-quantisation of the weights (lora.py:142, :50) costs no launch of its own and no extra round of workgroups.
+template <int PREP>   // 0: no weight rows; 1: fp16 limb rows; 2: int8 level rows (SPQ_PATH_I8)
+__global__ __launch_bounds__(256, 2) void xpass_rows16_kernel(XPassArgs a, PrepArgs pa, int prep_rows) {
   extern __shared__ __attribute__((aligned(16))) char xsm[];
   constexpr int CH = XP16R_CH;
   char* xs = xsm;
@@ -757,6 +853,27 @@ __global__ __launch_bounds__(256, 2) void xpass_rows16_kernel(XPassArgs a) {
   for (int p0 = 0; p0 < a.K; p0 += CH * 64) {
     const int nch = min(CH, (a.K - p0) / 64);
     for (int c = 0; c < nch; ++c) glds16(x_src + p0 + c * 64, xs + c * (XR16 * 256) + w * 1024);
+    if (PREP && p0 == 0) {
+      // weight rows of this workgroup, while the first panel's copies are in flight (their latency and the rows' load latency
+      // overlap).  The rows' LoRA-B columns B[j][n0 .. n0+nrows) are short contiguous runs: staged [row][j] in LDS (the second
+      // FQ(A)^T buffer is not in use yet) instead of one strided scalar read per (row, j) from every wave.
+      const int n0 = (int)blockIdx.x * prep_rows;
+      const int np = (pa.N + GN - 1) / GN * GN;
+      const int nrows = min(prep_rows, np - n0);
+      const float* sbw = nullptr;
+      if (pa.B && nrows > 0) {
+        float* sB = reinterpret_cast<float*>(as + XP_AS);
+        const int nbv = min(nrows, pa.N - n0);
+        for (int e = threadIdx.x; e < pa.r * nbv; e += 256) {
+          const int j = e / nbv, i = e - j * nbv;
+          sB[i * pa.Rp + j] = pa.B[(int64_t)j * pa.N + n0 + i];
+        }
+        __syncthreads();
+        sbw = sB;
+      }
+      for (int i = (int)(threadIdx.x >> 6); i < nrows; i += 4)
+        prep_row_wave<(PREP == 1 ? 0 : 1), 4>(pa, n0 + i, threadIdx.x & 63, (sbw && n0 + i < pa.N) ? sbw + i * pa.Rp : nullptr);
+    }
     for (int k = tid; k < nch * 64; k += 256) {
       sxs[k] = a.x_pc ? a.sx[p0 + k] : a.sx[0];
       sxs[CH * 64 + k] = (a.limbs || a.lora_fq) ? (a.x_pc ? a.zx[p0 + k] : a.zx[0]) : 0.f;
@@ -1523,12 +1640,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
 // -------------------------------------------------------------------------------------------------------------------
 constexpr int T128_STAGE_A = 128 * GK * 2;                 // 16 KB
 constexpr int T128_STAGE = T128_STAGE_A + 2 * STAGE_B;     // 48 KB
-constexpr int T128_LDS = T128_STAGE + 4 * EPI_WAVE;        // + 9 KB
+// The epilogue's per-wave transpose slices live INSIDE the stage buffer (free once the tile's last stage has been read), so a
+// workgroup needs 48 KB and THREE share a CU (the kernel takes 164-168 VGPRs: three waves per SIMD fit).  Measured: time per
+// stage per workgroup (~1.9 us) is mostly copy issue -> landed latency and barriers, hardly the 0.5 us of MFMAs, so a third
+// workgroup per CU fills what two leave idle.  T128_WGS = 2 keeps the separate 9-KB epilogue region (the round-1 kernel).
+#ifndef T128_WGS
+#define T128_WGS 3
+#endif
+constexpr bool T128_DEFER = T128_WGS == 3;
+constexpr int T128_LDS = T128_DEFER ? T128_STAGE : T128_STAGE + 4 * EPI_WAVE;
 #ifndef T128_GROUP_M
 #define T128_GROUP_M 8      // measured at the headline shape: 8 -> 81.5 us, 16 -> 82.9, 32 -> 84.5, 4 -> 84.5
 #endif
 template <int AL, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f16x2_t128_kernel(GemmF16Args g) {
+__global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1632,21 +1757,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_t128_kernel(GemmF16Args g) 
     const bool more = pn < nwg;
     int nbm = 0, nbn = 0;
     if (more) tile_of(pn, nbm, nbn);
-    float4 ep_rs[2], ep_bv[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
-      ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
-      if (n < g.N) {
-        ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);
-        if (AL == 2) { ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale; }
-        if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
-      }
-    }
     for (int t = 0; t < nl; t += 2) {
       stage(true, true, t + 1, bm, bn);
       const bool last = (t + 2 == T);
-      stage(false, !last || more, last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
+      stage(false, !last || (more && !T128_DEFER), last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
     }
     if (nl > 0) {
 #pragma unroll
@@ -1662,17 +1776,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_t128_kernel(GemmF16Args g) 
     if (AL == 1) {
       for (int t = nl; t < T; ++t) {
         const bool last = (t + 1 == T);
-        stage(true, !last || more, last ? 0 : t + 1, last ? nbm : bm, last ? nbn : bn);
+        stage(true, !last || (more && !T128_DEFER), last ? 0 : t + 1, last ? nbm : bm, last ? nbn : bn);
       }
     } else {
       for (int t = nl; t < T; t += 2) {
         stage(true, true, t + 1, bm, bn);
         const bool last = (t + 2 == T);
-        stage(false, !last || more, last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
+        stage(false, !last || (more && !T128_DEFER), last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
       }
     }
-    {                                                        // epilogue (the next tile's first stage is already in flight)
-      char* eb = smem + T128_STAGE + w * EPI_WAVE;
+    // epilogue operands: fetched here, not at the tile's start (16 registers that three waves per SIMD do not leave through
+    // the stage loop); the CU's other workgroups cover the load's latency
+    float4 ep_rs[2], ep_bv[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
+      ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
+      if (n < g.N) {
+        ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);
+        if (AL == 2) { ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale; }
+        if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
+      }
+    }
+    {                                                        // epilogue
+      char* eb = smem + (T128_DEFER ? 0 : T128_STAGE) + w * EPI_WAVE;     // T128_DEFER: inside the (now free) stage buffer
       const int c4 = (lane & 7) * 4;
       const bool interior = (bm + 128 <= g.M) && (bn + GN <= g.N);
 #pragma unroll
@@ -1703,6 +1830,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_t128_kernel(GemmF16Args g) 
       }
     }
     if (!more) break;
+    if (T128_DEFER) {                                       // the slices are done with: the next tile's first stage may land on them
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+      issue(0, nbm, nbn);
+    }
     p = pn; bm = nbm; bn = nbn;
   }
 }
@@ -2106,25 +2238,74 @@ static PrepLayout make_prep_layout(int64_t N, int64_t K, int64_t r) {
   return L;
 }
 
+// SPQ_PATH_I8: [int8 plane Np x Kp][Bhi][Blo][bscale Np floats]
+struct PrepLayoutI8 { int64_t Np, Kp, Rp; int nl; size_t plane, off_bhi, off_blo, off_bscale, total; };
+static PrepLayoutI8 make_prep_layout_i8(int64_t N, int64_t K, int64_t r, int nl) {
+  PrepLayoutI8 L;
+  L.Np = pad_to(N, GN); L.Kp = pad_to(K, GK); L.Rp = r > 0 ? pad_to(r, GK) : 0; L.nl = nl;
+  L.plane = (size_t)L.Np * L.Kp;                           // a multiple of 8192
+  size_t o = (size_t)nl * L.plane;
+  L.off_bhi = o; o += pad_to((size_t)L.Np * L.Rp * 2, 256);
+  L.off_blo = o; o += pad_to((size_t)L.Np * L.Rp * 2, 256);
+  L.off_bscale = o; o += pad_to((size_t)L.Np * 4, 256);
+  L.total = o + 256;
+  return L;
+}
+static inline int i8_limbs_of(int path) { return path == SPQ_PATH_I8 ? 1 : 0; }
+
 static bool f16x2_shape_ok(int64_t M, int64_t K, int64_t N, int64_t r) {
   return r <= 128 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30);
 }
 
+// Per-DEVICE host state (one process may drive several GPUs): the CU count that sizes the persistent grids, and which groups of
+// kernels have had their dynamic-LDS limit raised (hipFuncSetAttribute is kept per function per device).
+constexpr int kMaxDevices = 64;
+static std::mutex g_dev_mu;
+static int g_dev_cus[kMaxDevices];
+static unsigned g_dev_attr[kMaxDevices];
+static int current_device() { int dev = 0; if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; } return dev & (kMaxDevices - 1); }
+
 // persistent grid: one workgroup per CU (a multiple of 8 so that p % 8 stays the XCD label across iterations)
 unsigned gemm_grid(int ntiles) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) cus = n / 8 * 8;
-    else cus = 256;
+  const int dev = current_device();
+  int cus;
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (g_dev_cus[dev] == 0) {
+      int n = 0;
+      g_dev_cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) ? n / 8 * 8 : 256;
+    }
+    cus = g_dev_cus[dev];
   }
   return (unsigned)(ntiles < cus ? ntiles : cus);
 }
 
+// true exactly once per (device, group): the caller then sets the group's function attributes (under the same lock, so a second
+// host thread cannot launch on this device before they are in place)
+struct AttrOnce {
+  std::unique_lock<std::mutex> lk;
+  bool first;
+  AttrOnce(int group) : lk(g_dev_mu) {
+    const int dev = current_device();
+    first = !(g_dev_attr[dev] & (1u << group));
+    g_dev_attr[dev] |= 1u << group;
+  }
+};
+
+int prepare_fill(const spq_prepare_args* q, PrepArgs& a, int& at_blocks, bool& wave_ok);
+
 int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   const bool x3 = a->path == SPQ_PATH_F16X3;
-  if (x3) {
+  const int i8nl = i8_limbs_of(a->path);
+  if (i8nl) {
+    if (!(a->quantize_input && a->qtype == SPQ_MINMAX && a->symmetric && a->bits >= 2 && a->bits <= 8)) {
+      set_error("spq_linear_lora_fwd: the int8 operand paths need a symmetric minmax input quantizer with 2..8 bits "
+                "(got qtype=%d symmetric=%d bits=%d quantize_input=%d)", a->qtype, a->symmetric, a->bits, a->quantize_input);
+      return SPQ_ERR_UNSUPPORTED;
+    }
+    if (a->x_per_channel) { set_error("spq_linear_lora_fwd: SPQ_PATH_I8 needs a per-tensor input scale"); return SPQ_ERR_UNSUPPORTED; }
+    if (a->prepare && a->prepare->path != a->path) { set_error("spq_linear_lora_fwd: prepare args are for another operand path"); return SPQ_ERR_INVALID; }
+  } else if (x3) {
     if (!((!a->quantize_input || (a->bits >= 1 && a->bits <= 24)) && a->x_limb_scale)) {
       set_error("spq_linear_lora_fwd: SPQ_PATH_F16X3 needs x_limb_scale (and 1..24 bits when quantize_input is set)");
       return SPQ_ERR_UNSUPPORTED;
@@ -2166,31 +2347,64 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   if (a->path == SPQ_PATH_U8X2 && (a->N & 3) != 0) { set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 needs N %% 4 == 0"); return SPQ_ERR_UNSUPPORTED; }
   if (a->path == SPQ_PATH_U8X2 && a->epilogue != SPQ_EPILOGUE_NONE) { set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 has no fused epilogue"); return SPQ_ERR_UNSUPPORTED; }
   const bool a8 = a->path == SPQ_PATH_U8X2;   // levels as bytes + 3-slot ring kernel (opt-in)
-  x.a8 = a8 ? 1 : 0;
+  x.a8 = i8nl ? 2 : (a8 ? 1 : 0);
   const unsigned xgrid = (unsigned)((a->M + XR - 1) / XR);
   const bool panel_ok = (a->K % 64 == 0) && L.Rp <= 64 && aligned16(a->x) && (a->r == 0 || aligned16(a->a_prep)) && aligned16(x.sx) &&
                         aligned16(x.zx);
   const bool do_xpass = a->stage != SPQ_STAGE_CONTRACTION, do_gemm = a->stage != SPQ_STAGE_ACTIVATIONS;
+  // a->prepare: the weight-side operands are (re)made by this call.  When the 16-row activation kernel runs and every one of
+  // its workgroups gets at most 8 weight rows, the row work rides inside that kernel (FQ(A)^T, which the pass itself consumes,
+  // goes first as a launch of a few dozen workgroups); otherwise the ordinary preparation launch is issued first.
+  PrepArgs pa;
+  int prep_rows = 0, at_blocks = 0;
+  static int rows16 = -1, fuse_prep = -1;
+  if (rows16 < 0) {
+    const char* e = getenv("SPQ_XPASS_ROWS16");
+    rows16 = (e && e[0] == '0') ? 0 : 1;
+    fuse_prep = 1;      // a->prepare asks for it; the host side decides (sp_linear.py: fuse_prepare)
+  }
+  const bool use_rows16 = panel_ok && !(x.ascale && a->r > 0) && rows16 && xgrid < 2 * gemm_grid(1 << 30);
+  if (a->prepare && do_xpass) {
+    bool wave_ok = false;
+    int prc = prepare_fill(a->prepare, pa, at_blocks, wave_ok);
+    if (prc) return prc;
+    if (a->prepare->N != a->N || a->prepare->K != a->K || a->prepare->r < a->r) { set_error("spq_linear_lora_fwd: prepare args describe another layer"); return SPQ_ERR_INVALID; }
+    const int64_t xb = (a->M + XR16 - 1) / XR16;
+    const int64_t rows_each = (pad_to(a->N, GN) + xb - 1) / xb;
+    if (fuse_prep && use_rows16 && wave_ok && rows_each <= 8 && a->K <= 1024) {   // the in-pass row code covers K <= 1024
+      prep_rows = (int)rows_each;
+      if (at_blocks) {
+        fq_transpose_kernel<<<(unsigned)at_blocks, 256, 0, st>>>(pa);
+        prc = check_launch("spq_linear_lora_fwd(FQ(A)^T)");
+        if (prc) return prc;
+      }
+    } else {
+      prc = spq_prepare_f16x2_args(a->prepare, (spq_stream_t)st);
+      if (prc) return prc;
+    }
+  } else if (a->prepare && !do_xpass) {
+    set_error("spq_linear_lora_fwd: prepare args go with the activation stage");
+    return SPQ_ERR_INVALID;
+  }
   if (!do_xpass) {
     // the activation pass of this call ran earlier (same arguments, same workspace)
   } else if (panel_ok) {
-    static bool xattr = false;
-    if (!xattr) {
+    if (AttrOnce once(0); once.first) {
       hipError_t e = hipFuncSetAttribute((const void*)xpass_panel_kernel<XP_CHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, XP_LDS);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(xpass LDS %d B): %s", XP_LDS, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
       (void)hipFuncSetAttribute((const void*)xpass_panel_kernel<XP_CHUNKS_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, xp_lds(XP_CHUNKS_SMALL));
       (void)hipFuncSetAttribute((const void*)xpass_panel16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP16_LDS);
-      xattr = true;
-    }
-    static int rows16 = -1;
-    if (rows16 < 0) {
-      const char* e = getenv("SPQ_XPASS_ROWS16");
-      rows16 = (e && e[0] == '0') ? 0 : 1;
-      (void)hipFuncSetAttribute((const void*)xpass_rows16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP16R_LDS);
+      (void)hipFuncSetAttribute((const void*)xpass_rows16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, XP16R_LDS);
+      (void)hipFuncSetAttribute((const void*)xpass_rows16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, XP16R_LDS);
+      (void)hipFuncSetAttribute((const void*)xpass_rows16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, XP16R_LDS);
     }
     if (x.ascale && a->r > 0) xpass_panel16_kernel<<<xgrid, 512, XP16_LDS, st>>>(x);
-    else if (rows16 && xgrid < 2 * gemm_grid(1 << 30))
-      xpass_rows16_kernel<<<(unsigned)((a->M + XR16 - 1) / XR16), 256, XP16R_LDS, st>>>(x);
+    else if (use_rows16 && prep_rows > 0) {
+      const unsigned xg16 = (unsigned)((a->M + XR16 - 1) / XR16);
+      if (pa.nl == 1) xpass_rows16_kernel<2><<<xg16, 256, XP16R_LDS, st>>>(x, pa, prep_rows);
+      else xpass_rows16_kernel<1><<<xg16, 256, XP16R_LDS, st>>>(x, pa, prep_rows);
+    } else if (use_rows16)
+      xpass_rows16_kernel<0><<<(unsigned)((a->M + XR16 - 1) / XR16), 256, XP16R_LDS, st>>>(x, pa, 0);
     else if (xgrid >= 2 * gemm_grid(1 << 30)) xpass_panel_kernel<XP_CHUNKS_SMALL><<<xgrid, 512, xp_lds(XP_CHUNKS_SMALL), st>>>(x);
     else xpass_panel_kernel<XP_CHUNKS><<<xgrid, 512, XP_LDS, st>>>(x);
   } else if (L.Rp <= 64) xpass_kernel<2><<<xgrid, 256, 0, st>>>(x);
@@ -2198,6 +2412,41 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   int rc = check_launch("spq_linear_lora_fwd(xpass)");
   if (rc || !do_gemm) return rc;
 
+  if (i8nl) {
+    const PrepLayoutI8 P8 = make_prep_layout_i8(a->N, a->K, a->r, i8nl);
+    GemmI8Args q;
+    q.qx = reinterpret_cast<const signed char*>(x.qx); q.W = reinterpret_cast<const signed char*>(wp); q.plane_stride = (int64_t)P8.plane;
+    q.thi = x.thi; q.tlo = x.tlo;
+    q.Bhi = (const _Float16*)(wp + P8.off_bhi); q.Blo = (const _Float16*)(wp + P8.off_blo);
+    q.rowinv = x.rowinv; q.rowscale = a->w_rowscale; q.bscale = (const float*)(wp + P8.off_bscale); q.bias = a->bias; q.y = a->y;
+    q.M = (int)a->M; q.N = (int)a->N; q.Kp = (int)L.Kp; q.Rp = lora_up ? (int)L.Rp : 0;
+    q.tiles_m = (int)(L.Mp / GM); q.tiles_n = (int)(P8.Np / GN); q.epilogue = a->epilogue;
+    // 128-deep stages (whole cache lines, half as many stages: measured 50-53 us against 56-59 at the c_fc shape) whenever K
+    // allows; the 64-deep ring kernel otherwise
+    const bool k128 = (L.Kp % 128) == 0;
+    if (AttrOnce once(1); once.first) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_kernel<1, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS);
+      if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %d B): %s", I8_LDS, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
+      (void)hipFuncSetAttribute((const void*)gemm_i8_kernel<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, I8_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_i8_k128_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, i8k_lds(1));
+      (void)hipFuncSetAttribute((const void*)gemm_i8_k128_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, i8k_lds(1));
+    }
+    const bool gelu8 = a->epilogue == SPQ_EPILOGUE_GELU;
+    if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
+    if (k128) {
+      const int ntiles = 2 * q.tiles_m * q.tiles_n;
+      const unsigned cus2 = 2 * gemm_grid(1 << 30);
+      const unsigned g128 = (unsigned)ntiles < cus2 ? (unsigned)ntiles : cus2;
+      if (gelu8) gemm_i8_k128_kernel<1, 1><<<g128, 256, i8k_lds(1), st>>>(q);
+      else gemm_i8_k128_kernel<1, 0><<<g128, 256, i8k_lds(1), st>>>(q);
+    } else {
+      const unsigned grid8 = gemm_grid(q.tiles_m * q.tiles_n);
+      if (gelu8) gemm_i8_kernel<1, 0, 1><<<grid8, I8_THREADS, I8_LDS, st>>>(q);
+      else gemm_i8_kernel<1, 0, 0><<<grid8, I8_THREADS, I8_LDS, st>>>(q);
+    }
+    if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
+    return check_launch("spq_linear_lora_fwd(gemm_i8)");
+  }
   if (a8) {
     GemmU8Args u;
     u.qx = reinterpret_cast<const unsigned char*>(x.qx); u.thi = x.thi; u.tlo = x.tlo;
@@ -2206,11 +2455,9 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     u.rowinv = x.rowinv; u.rowscale = a->w_rowscale; u.bias = a->bias; u.y = a->y;
     u.M = (int)a->M; u.N = (int)a->N; u.Kp = (int)L.Kp; u.Rp = lora_up ? (int)L.Rp : 0;
     u.tiles_m = (int)(L.Mp / GM); u.tiles_n = (int)(P.Np / GN);
-    static bool uattr = false;
-    if (!uattr) {
+    if (AttrOnce once(2); once.first) {
       hipError_t e = hipFuncSetAttribute((const void*)gemm_u8x2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, U8_LDS);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %d B): %s", U8_LDS, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
-      uattr = true;
     }
     if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
     gemm_u8x2_kernel<0><<<gemm_grid(u.tiles_m * u.tiles_n), GEMM_THREADS, U8_LDS, st>>>(u);
@@ -2225,12 +2472,18 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   g.M = (int)a->M; g.N = (int)a->N; g.Kp = (int)L.Kp; g.Rp = lora_up ? (int)L.Rp : 0;
   g.tiles_m = (int)(L.Mp / GM); g.tiles_n = (int)(P.Np / GN); g.dbg = nullptr;
   g.xl = x.xl; g.xscale = a->x_limb_scale; g.a_limbs = x3 ? 2 : 1;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (AttrOnce once(3); once.first) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_f16x2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        GEMM_LDS);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %d B): %s", GEMM_LDS, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
-    attr_set = true;
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
   }
   if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
   // default: the 16x16x32 variant (measured 85 us vs 90 us for the 32x32x16 one on the headline shape, same cycles per
@@ -2239,12 +2492,6 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   if (mfma16 < 0) {
     const char* e = getenv("SPQ_MFMA16");
     mfma16 = (e && e[0] == '0') ? 0 : 1;
-    if (mfma16) {
-      (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-      (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    }
   }
   if (x3 && !mfma16) { set_error("spq_linear_lora_fwd: SPQ_PATH_F16X3 needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
   const bool gelu = a->epilogue == SPQ_EPILOGUE_GELU;
@@ -2253,10 +2500,6 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   if (t128 < 0) {
     const char* e = getenv("SPQ_GEMM_T128");
     t128 = !e ? 2 : (e[0] == '1' ? 1 : 0);     // unset: by shape (below), 1: always, 0: never
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
   }
   if ((a->N & 3) != 0 && !mfma16) { set_error("spq_linear_lora_fwd: N %% 4 != 0 needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
   // measured (tools/config_bench.py): two decoupled 128x128 workgroups per CU win 1.5-3 % while M <= 8192 and lose 3-6 % at
@@ -2264,7 +2507,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   const bool use_t128 = t128 == 1 || (t128 == 2 && !x3 && a->M <= 12288);
   if (use_t128 && mfma16 && (a->N & 3) == 0) {
     const int ntiles = 2 * g.tiles_m * g.tiles_n;
-    const unsigned cus2 = 2 * gemm_grid(1 << 30);
+    const unsigned cus2 = T128_WGS * gemm_grid(1 << 30);
     const unsigned grid128 = (unsigned)ntiles < cus2 ? (unsigned)ntiles : cus2;
     if (x3 && gelu) gemm_f16x2_t128_kernel<2, 1><<<grid128, 256, T128_LDS, st>>>(g);
     else if (x3) gemm_f16x2_t128_kernel<2, 0><<<grid128, 256, T128_LDS, st>>>(g);
@@ -2292,6 +2535,77 @@ extern "C" size_t spq_prep_f16x2_bytes(int64_t N, int64_t K, int64_t r) {
   return make_prep_layout(N, K, r).total;
 }
 
+extern "C" size_t spq_prep_bytes(int64_t N, int64_t K, int64_t r, int path) {
+  if (N <= 0 || K <= 0 || r < 0) return 0;
+  const int nl = i8_limbs_of(path);
+  return nl ? make_prep_layout_i8(N, K, r, nl).total : make_prep_layout(N, K, r).total;
+}
+
+namespace spq {
+// validation + PrepArgs of one spq_prepare_args; at_blocks = FQ(A)^T tiles, wave_ok = the one-wave-per-row kernel applies
+int prepare_fill(const spq_prepare_args* q, PrepArgs& a, int& at_blocks, bool& wave_ok) {
+  SPQ_REQUIRE(q, "spq_prepare_f16x2: null args");
+  SPQ_REQUIRE(q->W && q->sw && q->zw && q->sx && q->w_prep && q->w_rowscale, "spq_prepare_f16x2: null pointer");
+  SPQ_REQUIRE(q->N > 0 && q->K > 0 && q->r >= 0, "spq_prepare_f16x2: bad shape");
+  SPQ_REQUIRE(q->r == 0 || (q->B && q->sb && q->zb), "spq_prepare_f16x2: LoRA operands missing");
+  SPQ_REQUIRE(!q->A || (q->sa && q->za && q->a_prep), "spq_prepare_f16x2: LoRA-A quantizer parameters / output missing");
+  SPQ_REQUIRE(q->w_bits >= 1 && q->b_bits >= 0 && q->a_bits >= 0, "spq_prepare_f16x2: bad bit-width");
+  const int64_t N = q->N, K = q->K, r = q->r;
+  if (!f16x2_shape_ok(1, K, N, r)) { set_error("spq_prepare_f16x2: needs LoRA rank <= 128 (got r=%lld)", (long long)r); return SPQ_ERR_UNSUPPORTED; }
+  const int nl = i8_limbs_of(q->path);
+  SPQ_REQUIRE(nl || q->path == 0 || q->path == SPQ_PATH_F16X2 || q->path == SPQ_PATH_U8X2 || q->path == SPQ_PATH_F16X3,
+              "spq_prepare_f16x2: unknown operand path %d", q->path);
+  const PrepLayout P = make_prep_layout(N, K, r);
+  const PrepLayoutI8 P8 = make_prep_layout_i8(N, K, r, nl);
+  const size_t need = nl ? P8.total : P.total;
+  if (q->w_prep_bytes < need || !aligned16(q->w_prep)) { set_error("spq_prepare_f16x2: buffer too small (%zu < %zu)", q->w_prep_bytes, need); return SPQ_ERR_WORKSPACE; }
+  char* wp = (char*)q->w_prep;
+  a.W = q->W; a.sw = q->sw; a.zw = q->zw; a.B = r > 0 ? q->B : nullptr; a.sb = q->sb; a.zb = q->zb; a.sx = q->sx;
+  a.nl = nl; a.W8 = nullptr; a.plane_stride = 0; a.bscale = nullptr;
+  if (nl) {
+    if (!(q->w_qtype == SPQ_MINMAX && q->w_symmetric && q->w_bits >= 2 && q->w_bits <= 8 && !q->x_per_channel)) {
+      set_error("spq_prepare_f16x2: SPQ_PATH_I8 needs symmetric minmax weights of <= 8 bits and a per-tensor input scale");
+      return SPQ_ERR_UNSUPPORTED;
+    }
+    a.Whi = a.Wlo = nullptr;
+    a.W8 = (signed char*)wp; a.plane_stride = (int64_t)P8.plane;
+    a.Bhi = P8.Rp ? (_Float16*)(wp + P8.off_bhi) : nullptr; a.Blo = P8.Rp ? (_Float16*)(wp + P8.off_blo) : nullptr;
+    a.bscale = (float*)(wp + P8.off_bscale);
+  } else {
+    a.Whi = (_Float16*)(wp + P.off_whi); a.Wlo = (_Float16*)(wp + P.off_wlo);
+    a.Bhi = P.Rp ? (_Float16*)(wp + P.off_bhi) : nullptr; a.Blo = P.Rp ? (_Float16*)(wp + P.off_blo) : nullptr;
+  }
+  a.rowscale = q->w_rowscale;
+  a.N = (int)N; a.K = (int)K; a.r = (int)r; a.Kp = (int)P.Kp; a.Rp = (int)P.Rp;
+  a.w_pc = q->w_per_channel; a.w_bits = q->w_bits; a.w_qtype = q->w_qtype; a.w_sym = q->w_symmetric;
+  a.b_pc = q->b_per_channel; a.b_bits = q->b_bits; a.b_qtype = q->b_qtype; a.b_sym = q->b_symmetric;
+  a.x_pc = q->x_per_channel; a.scaling = q->scaling;
+  a.A = q->A; a.sa = q->sa; a.za = q->za; a.aT = q->a_prep;
+  a.a_pc = q->a_per_channel; a.a_bits = q->a_bits; a.a_qtype = q->a_qtype; a.a_sym = q->a_symmetric;
+  at_blocks = (r > 0 && q->A) ? (int)(((r + 31) / 32) * ((K + 31) / 32)) : 0;   // A == NULL: FQ(A)^T is made elsewhere
+  wave_ok = (K % 4 == 0) && K <= 4 * 64 * PREP_MAXI && aligned16(q->W) && (!q->x_per_channel || aligned16(q->sx)) && r <= 128;
+  a.row_blocks = wave_ok ? (int)(P.Np / 4) : (int)P.Np;
+  if (nl && !wave_ok) {
+    set_error("spq_prepare_f16x2: the int8 operand paths need K %% 4 == 0, K <= %d and 16-byte aligned W / sx", 4 * 64 * PREP_MAXI);
+    return SPQ_ERR_UNSUPPORTED;
+  }
+  return SPQ_OK;
+}
+}  // namespace spq
+
+extern "C" int spq_prepare_f16x2_args(const spq_prepare_args* q, spq_stream_t stream) {
+  PrepArgs a;
+  int at_blocks = 0;
+  bool wave_ok = false;
+  const int rc = prepare_fill(q, a, at_blocks, wave_ok);
+  if (rc) return rc;
+  const unsigned grid = (unsigned)(a.row_blocks + at_blocks);
+  if (a.nl == 1) prep_wave_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a, at_blocks);
+  else if (wave_ok) prep_wave_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a, at_blocks);
+  else prep_f16x2_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  return check_launch("spq_prepare_f16x2");
+}
+
 extern "C" int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const float* sw, const float* zw,
                                  int w_per_channel, int w_bits, int w_qtype, int w_symmetric, const float* B,
                                  int64_t r, const float* sb, const float* zb, int b_per_channel, int b_bits,
@@ -2299,36 +2613,14 @@ extern "C" int spq_prepare_f16x2(const float* W, int64_t N, int64_t K, const flo
                                  const float* za, int a_per_channel, int a_bits, int a_qtype, int a_symmetric,
                                  const float* sx, int x_per_channel, void* w_prep, size_t w_prep_bytes,
                                  float* w_rowscale, float* a_prep, spq_stream_t stream) {
-  SPQ_REQUIRE(W && sw && zw && sx && w_prep && w_rowscale, "spq_prepare_f16x2: null pointer");
-  SPQ_REQUIRE(N > 0 && K > 0 && r >= 0, "spq_prepare_f16x2: bad shape");
-  SPQ_REQUIRE(r == 0 || (B && sb && zb), "spq_prepare_f16x2: LoRA operands missing");
-  SPQ_REQUIRE(!A || (sa && za && a_prep), "spq_prepare_f16x2: LoRA-A quantizer parameters / output missing");
-  SPQ_REQUIRE(w_bits >= 1 && b_bits >= 0 && a_bits >= 0, "spq_prepare_f16x2: bad bit-width");
-  if (!f16x2_shape_ok(1, K, N, r)) { set_error("spq_prepare_f16x2: needs LoRA rank <= 128 (got r=%lld)", (long long)r); return SPQ_ERR_UNSUPPORTED; }
-  const PrepLayout P = make_prep_layout(N, K, r);
-  if (w_prep_bytes < P.total || !aligned16(w_prep)) { set_error("spq_prepare_f16x2: buffer too small (%zu < %zu)", w_prep_bytes, P.total); return SPQ_ERR_WORKSPACE; }
-  char* wp = (char*)w_prep;
-  PrepArgs a;
-  a.W = W; a.sw = sw; a.zw = zw; a.B = r > 0 ? B : nullptr; a.sb = sb; a.zb = zb; a.sx = sx;
-  a.Whi = (_Float16*)(wp + P.off_whi); a.Wlo = (_Float16*)(wp + P.off_wlo);
-  a.Bhi = P.Rp ? (_Float16*)(wp + P.off_bhi) : nullptr; a.Blo = P.Rp ? (_Float16*)(wp + P.off_blo) : nullptr;
-  a.rowscale = w_rowscale;
-  a.N = (int)N; a.K = (int)K; a.r = (int)r; a.Kp = (int)P.Kp; a.Rp = (int)P.Rp;
-  a.w_pc = w_per_channel; a.w_bits = w_bits; a.w_qtype = w_qtype; a.w_sym = w_symmetric;
-  a.b_pc = b_per_channel; a.b_bits = b_bits; a.b_qtype = b_qtype; a.b_sym = b_symmetric;
-  a.x_pc = x_per_channel; a.scaling = scaling;
-  a.A = A; a.sa = sa; a.za = za; a.aT = a_prep;
-  a.a_pc = a_per_channel; a.a_bits = a_bits; a.a_qtype = a_qtype; a.a_sym = a_symmetric;
-  const int at_blocks = (r > 0 && A) ? (int)(((r + 31) / 32) * ((K + 31) / 32)) : 0;   // A == NULL: FQ(A)^T is made elsewhere
-  const bool wave_ok = (K % 4 == 0) && K <= 4 * 64 * PREP_MAXI && aligned16(W) && (!x_per_channel || aligned16(sx)) && r <= 128;
-  if (wave_ok) {
-    a.row_blocks = (int)(P.Np / 4);
-    prep_f16x2_wave_kernel<<<(unsigned)(a.row_blocks + at_blocks), 256, 0, (hipStream_t)stream>>>(a);
-  } else {
-    a.row_blocks = (int)P.Np;
-    prep_f16x2_kernel<<<(unsigned)(a.row_blocks + at_blocks), 256, 0, (hipStream_t)stream>>>(a);
-  }
-  return check_launch("spq_prepare_f16x2");
+  spq_prepare_args q;
+  q.W = W; q.N = N; q.K = K; q.sw = sw; q.zw = zw; q.w_per_channel = w_per_channel; q.w_bits = w_bits; q.w_qtype = w_qtype;
+  q.w_symmetric = w_symmetric; q.B = B; q.r = r; q.sb = sb; q.zb = zb; q.b_per_channel = b_per_channel; q.b_bits = b_bits;
+  q.b_qtype = b_qtype; q.b_symmetric = b_symmetric; q.scaling = scaling; q.A = A; q.sa = sa; q.za = za;
+  q.a_per_channel = a_per_channel; q.a_bits = a_bits; q.a_qtype = a_qtype; q.a_symmetric = a_symmetric; q.sx = sx;
+  q.x_per_channel = x_per_channel; q.w_prep = w_prep; q.w_prep_bytes = w_prep_bytes; q.w_rowscale = w_rowscale; q.a_prep = a_prep;
+  q.path = SPQ_PATH_F16X2;
+  return spq_prepare_f16x2_args(&q, stream);
 }
 
 extern "C" int spq_prepare_cpt(const float* W, int64_t N, int64_t K, const float* sw, const float* zw, int w_per_channel,

@@ -159,11 +159,13 @@ class _LimbGemm:
 
 class _Prepared:
     """Weight-side GEMM operands of one bit-width plus the signature of what they were built from."""
-    __slots__ = ("sig", "path", "w", "w_rowscale", "a", "b", "r", "x_limb_scale", "ready", "a_limb_scale")
+    __slots__ = ("sig", "path", "w", "w_rowscale", "a", "b", "r", "x_limb_scale", "ready", "a_limb_scale", "pending", "keep")
 
     def __init__(self):
         self.sig = None
         self.w = self.w_rowscale = self.a = self.b = self.x_limb_scale = self.ready = self.a_limb_scale = None
+        self.pending = None      # _lib.PrepareArgs not launched yet: the forward that follows makes the operands itself
+        self.keep = None         # tensors the pending struct points into
         self.r = 0
 
 
@@ -210,6 +212,11 @@ class SPLinearWithLoRA(nn.Module):
         self.backward_limbs = True                # d/dx on the f16 MFMA limb kernel (False: fp32 MFMA kernel)
         # weight-side limb split on a side stream, under the activation pass (opt-in: measured slower)
         self.overlap_prepare = os.environ.get('SPQ_OVERLAP_PREPARE', '0') == '1'
+        # True: a re-quantising forward (training mode, or cache_operands off) makes the weight-side operands inside its
+        # activation pass (spq_fwd_args.prepare) instead of launching their preparation.  Off by default: measured 3-4 us
+        # SLOWER per forward at the headline shape (the extra FQ(A)^T launch and the fatter activation kernel cost more than
+        # the preparation launch they replace); SPQ_FUSE_PREPARE=1 turns it on
+        self.fuse_prepare = os.environ.get('SPQ_FUSE_PREPARE', '0') == '1'
         self._bwd_gemm = None
         self._wq_t = None                         # (signature, FQ(W)^T) for the backward, see _fq_weight_t
         self._last_t = None                       # LoRA-down product of the last training forward (consumed by autograd)
@@ -342,7 +349,10 @@ class SPLinearWithLoRA(nn.Module):
             ev_gemm_begin=self._gemm_events[0] if self._gemm_events else None,
             ev_gemm_end=self._gemm_events[1] if self._gemm_events else None, t_out=_lib.ptr(self._last_t),
             a_limb_scale=_lib.ptr(prep.a_limb_scale) if r else None)
-        if activation == 'gelu' and prep.path in (_lib.PATH_F16X2, _lib.PATH_F16X3) and _MFMA16:
+        if prep.pending is not None:
+            a.prepare = ctypes.pointer(prep.pending)
+        if activation == 'gelu' and ((prep.path in (_lib.PATH_F16X2, _lib.PATH_F16X3) and _MFMA16)
+                                     or prep.path == _lib.PATH_I8):
             a.epilogue = _lib.EPILOGUE_GELU
             self._activation_fused = True
         with _lib.on_device(x.device):
@@ -354,6 +364,7 @@ class SPLinearWithLoRA(nn.Module):
                 prep.ready = None
                 a.stage = _lib.STAGE_CONTRACTION
             rc = lib.spq_linear_lora_fwd(ctypes.byref(a), st)
+        prep.pending = prep.keep = None
         _lib.check(rc, "spq_linear_lora_fwd")
         return y.view(*lead, N)
 
@@ -377,7 +388,17 @@ class SPLinearWithLoRA(nn.Module):
         # any other calibrated input quantizer (log, asymmetric, > 12 bit): FQ(x) as two fp16 limbs
         x3_ok = (quantize_input and not f16_ok and qx.quantizer_type in _lib.QTYPE_CODE and 1 <= qx.num_bits <= 16
                  and shape_ok and _MFMA16)               # the two-limb activation stages exist in the 16x16x32 kernel only
+        # int8 matrix cores (SPQ_PATH_I8): levels of <= 8 bits x the weight's own integer levels -- one product per algorithmic
+        # product at twice the f16 rate -- valid when those levels exist (symmetric minmax weights, <= 8 bit) and the input scale
+        # is per tensor (it then leaves the sum).  Measured 50-53 us against ~80 us for the contraction at the c_fc shape.
+        i8_ok = bool(f16_ok and qx.num_bits <= 8 and self.in_features % 4 == 0 and self.in_features <= 4096
+                     and qw is not None and qw.quantizer_type == 'minmax' and qw.symmetric and 2 <= qw.num_bits <= 8
+                     and qx.scale.numel() == 1)
+        if self.operand_path == _lib.PATH_I8:
+            return _lib.PATH_I8 if i8_ok else (_lib.PATH_F16X2 if f16_ok else (_lib.PATH_F16X3 if x3_ok else _lib.PATH_F32))
         if self.operand_path == _lib.PATH_AUTO:
+            if _AUTO_I8 and i8_ok:
+                return _lib.PATH_I8
             return _lib.PATH_F16X2 if f16_ok else (_lib.PATH_F16X3 if x3_ok else _lib.PATH_F32)
         if self.operand_path == _lib.PATH_F16X3:
             return _lib.PATH_F16X3 if (x3_ok or f16_ok) else _lib.PATH_F32
@@ -410,7 +431,7 @@ class SPLinearWithLoRA(nn.Module):
         sig = None
         if use_cache:                                   # (training re-quantises on every call: no signature needed)
             sig = [path, use_lora, _sig(W), qw._epoch, _sig(qw.scale), _sig(qw.zero_point)]
-            if path in (_lib.PATH_F16X2, _lib.PATH_U8X2, _lib.PATH_F16X3):
+            if path in _LIMB_PATHS:
                 sig += [qx._epoch, _sig(qx.scale), _sig(qx.zero_point)]
             if use_lora:
                 for q, t in ((lora.quantize_A, lora.lora_A), (lora.quantize_B, lora.lora_B)):
@@ -432,16 +453,18 @@ class SPLinearWithLoRA(nn.Module):
                 prep.w = qw(W.detach())                                                            # [N,K]
                 prep.b = _fq_transposed(lora.quantize_B, lora.lora_B.detach()) if use_lora else None  # [N,r]
             else:
-                self._prepare_f16x2(prep, qx, qw, lora, use_lora)
+                # re-quantising every call (training mode / cache off): hand the job to the forward, which spreads the row work
+                # over its activation pass instead of launching it (spq_fwd_args.prepare)
+                self._prepare_f16x2(prep, qx, qw, lora, use_lora, defer=not use_cache and self.fuse_prepare)
         prep.sig = sig
         self._prepared[ckey] = prep
         return prep
 
-    def _prepare_f16x2(self, prep, qx, qw, lora, use_lora):
+    def _prepare_f16x2(self, prep, qx, qw, lora, use_lora, defer=False):
         W = self.linear.weight.detach().contiguous()
         N, K, r = self.out_features, self.in_features, prep.r
         lib = _lib.load()
-        nbytes = lib.spq_prep_f16x2_bytes(N, K, r)
+        nbytes = lib.spq_prep_bytes(N, K, r, prep.path)
         if getattr(prep, "w", None) is None or prep.w.dtype != torch.uint8 or prep.w.numel() < nbytes:
             prep.w = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
         n_pad = (N + 127) // 128 * 128
@@ -473,9 +496,10 @@ class SPLinearWithLoRA(nn.Module):
         # The limb planes of W and B are needed by the contraction only, FQ(A)^T already by the activation pass: with
         # overlap on, FQ(A)^T is made on the current stream and the (much larger) W/B job on a side stream, so it runs
         # under the activation pass of the forward that follows; that forward waits for `prep.ready` before its contraction.
-        overlap = self.overlap_prepare and use_lora
+        overlap = self.overlap_prepare and use_lora and not defer
         cur = torch.cuda.current_stream(W.device)
         prep.ready = None
+        prep.pending = prep.keep = None
         if overlap:
             with torch.cuda.device(W.device):
                 rc = lib.spq_fakequant_transposed(
@@ -486,28 +510,33 @@ class SPLinearWithLoRA(nn.Module):
             side = _side_stream(W.device)
             side.wait_stream(cur)                          # the previous forward's contraction may still read the planes
             A = None
-        with torch.cuda.device(W.device), torch.cuda.stream(side if overlap else cur):
-            rc = lib.spq_prepare_f16x2(
-                W.data_ptr(), N, K, sw.data_ptr(), zw.data_ptr(), 1 if sw.numel() > 1 else 0,
-                int(qw.num_bits), _lib.QTYPE_CODE[qw.quantizer_type], 1 if qw.symmetric else 0,
-                _lib.ptr(B), r, _lib.ptr(sb), _lib.ptr(zb),
-                (1 if sb.numel() > 1 else 0) if qb else 0, int(qb.num_bits) if qb else 0,
-                _lib.QTYPE_CODE[qb.quantizer_type] if qb else 0, (1 if qb.symmetric else 0) if qb else 1,
-                float(lora.scaling) if use_lora else 0.0,
-                _lib.ptr(A), _lib.ptr(sa), _lib.ptr(za),
-                (1 if sa.numel() > 1 else 0) if qa else 0, int(qa.num_bits) if qa else 0,
-                _lib.QTYPE_CODE[qa.quantizer_type] if qa else 0, (1 if qa.symmetric else 0) if qa else 1,
-                sx_t.data_ptr(), 1 if sx_t.numel() > 1 else 0,
-                prep.w.data_ptr(), prep.w.numel(), prep.w_rowscale.data_ptr(), _lib.ptr(prep.a) if use_lora else None,
-                _lib.stream_ptr(W.device))
-            if overlap:
-                prep.ready = torch.cuda.Event()
-                prep.ready.record(side)
-        _lib.check(rc, "spq_prepare_f16x2")
+        pa = _lib.PrepareArgs(
+            W=W.data_ptr(), N=N, K=K, sw=sw.data_ptr(), zw=zw.data_ptr(), w_per_channel=1 if sw.numel() > 1 else 0,
+            w_bits=int(qw.num_bits), w_qtype=_lib.QTYPE_CODE[qw.quantizer_type], w_symmetric=1 if qw.symmetric else 0,
+            B=_lib.ptr(B), r=r, sb=_lib.ptr(sb), zb=_lib.ptr(zb), b_per_channel=(1 if sb.numel() > 1 else 0) if qb else 0,
+            b_bits=int(qb.num_bits) if qb else 0, b_qtype=_lib.QTYPE_CODE[qb.quantizer_type] if qb else 0,
+            b_symmetric=(1 if qb.symmetric else 0) if qb else 1, scaling=float(lora.scaling) if use_lora else 0.0,
+            A=_lib.ptr(A), sa=_lib.ptr(sa), za=_lib.ptr(za), a_per_channel=(1 if sa.numel() > 1 else 0) if qa else 0,
+            a_bits=int(qa.num_bits) if qa else 0, a_qtype=_lib.QTYPE_CODE[qa.quantizer_type] if qa else 0,
+            a_symmetric=(1 if qa.symmetric else 0) if qa else 1, sx=sx_t.data_ptr(), x_per_channel=1 if sx_t.numel() > 1 else 0,
+            w_prep=prep.w.data_ptr(), w_prep_bytes=prep.w.numel(), w_rowscale=prep.w_rowscale.data_ptr(),
+            a_prep=_lib.ptr(prep.a) if use_lora else None, path=prep.path)
+        if defer:
+            prep.pending, prep.keep = pa, (W, B, A, sw, zw, sb, zb, sa, za, sx_t)
+        else:
+            with torch.cuda.device(W.device), torch.cuda.stream(side if overlap else cur):
+                rc = lib.spq_prepare_f16x2_args(ctypes.byref(pa), _lib.stream_ptr(W.device))
+                if overlap:
+                    prep.ready = torch.cuda.Event()
+                    prep.ready.record(side)
+            _lib.check(rc, "spq_prepare_f16x2")
         prep.b = prep.w      # LoRA-B limbs live inside the same buffer
 
 
 _MFMA16 = os.environ.get('SPQ_MFMA16', '1')[:1] != '0'      # the library's kernel choice (spq_f16x2.hip)
+_LIMB_PATHS = (_lib.PATH_F16X2, _lib.PATH_U8X2, _lib.PATH_F16X3, _lib.PATH_I8)
+# SPQ_AUTO_I8=0: PATH_AUTO never picks the int8 operand path (then: F16X2 wherever it would be valid)
+_AUTO_I8 = os.environ.get('SPQ_AUTO_I8', '1')[:1] != '0'
 # SPQ_LORA_DOWN_F16=1: x . FQ(A) of the activation pass as fp16 limbs on the f16 matrix pipe (xpass_panel16_kernel).  Off by default:
 # its 200 VGPRs allow one workgroup per CU, and two resident workgroups of the fp32-MFMA kernel hide more latency
 _LORA_DOWN_F16 = os.environ.get('SPQ_LORA_DOWN_F16', '0') == '1'
@@ -571,8 +600,8 @@ class _SPLinearFunction(torch.autograd.Function):
         d/dW     = STE_W( g^T . FQ(x) )   (only if the base weight is trainable; main_sp.py:83 freezes it)
         d/dbias  = sum_m g
 
-    The M-contractions (d/dA, d/dB, d/dW) are plain library GEMMs (torch-ROCm); the N- and r-contractions run on the
-    fp32-MFMA kernel of this library.
+    Every contraction runs on this library's kernels: the M-contractions (d/dA, d/dB, d/dW) on spq_gemm_f32_tn, the N- and
+    r-contractions on the f16-limb / fp32-MFMA kernels (no vendor BLAS on the path).
     """
 
     @staticmethod
@@ -619,7 +648,8 @@ class _SPLinearFunction(torch.autograd.Function):
                 # W_eff^T = FQ(W)^T + s * FQ(A) . FQ(B)  [K, N] is formed once (0.3 GFLOP); log STE clamps the base term only
                 wq_t = module._fq_weight_t(qw)                                   # FQ(W)^T [K, N], kept while W is frozen
                 if ctx.use_lora and not log_x:
-                    w_t = torch.addmm(wq_t, aq, bq, alpha=s)
+                    # the rank-r update on this library's fp32-MFMA kernel (no vendor BLAS anywhere on the path)
+                    w_t = torch.add(wq_t, _gemm_nt(aq.contiguous(), bq.t().contiguous()), alpha=s)
                 else:
                     w_t = wq_t
                 if module._bwd_gemm is None:
@@ -657,7 +687,7 @@ class _SPLinearFunction(torch.autograd.Function):
                 gB = ste(_gemm_tn(t, g2, s), lora.quantize_B)
             if need_W:
                 xq = qx(x2) if (qx.num_bits < 32 and qx.calibrated and not qx.collecting_stats) else x2
-                gW = ste(g2.t() @ xq.reshape(-1, K), qw)
+                gW = ste(_gemm_tn(g2, xq.reshape(-1, K).contiguous()), qw)       # g^T . FQ(x) on spq_gemm_f32_tn
             if need_b:
                 gb = g2.sum(dim=0)
         return gx, gW, gb, gA, gB, None, None

@@ -52,7 +52,24 @@ def test_argument_validation_without_gpu(lib):
         pkg._lib.check(rc, "spq_fakequant")
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof of both argument structs as gcc lays include/spq.h out, against the ctypes mirrors."""
+    import subprocess
     import llm_qat_on_gpt2_amd as pkg
-    # 4 int64 + 6 int + 4 ptr + 5 ptr + float(+pad) + 2 ptr + size_t + 2 ptr + t_out + 3 int(+pad) + a_limb_scale
-    assert ctypes.sizeof(pkg._lib.FwdArgs) == 4 * 8 + 6 * 4 + 9 * 8 + 8 + 3 * 8 + 2 * 8 + 8 + 16 + 8
+    structs = {"spq_fwd_args": pkg._lib.FwdArgs, "spq_prepare_args": pkg._lib.PrepareArgs}
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "spq.h")}"', 'int main(void) {']
+    for cname, st in structs.items():
+        src.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            src.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src += ['  return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", str(c), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, st in structs.items():
+        assert int(out[cname]) == ctypes.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(st, fname).offset, f"{cname}.{fname}"
+

@@ -162,7 +162,8 @@ def test_layer_case(pkg, name, path):
         y2d = layer(t["x2"].reshape(-1, meta["K"])[:40].contiguous().to(DEV))
     assert tuple(y2.shape) == tuple(t["y_x2"].shape) and tuple(y2d.shape) == tuple(t["y_2d"].shape)
     f16_ok = qt == "minmax" and meta["bits"] <= 12
-    want = {"auto": pkg._lib.PATH_F16X2 if f16_ok else pkg._lib.PATH_F16X3, "f32": pkg._lib.PATH_F32,
+    i8_ok = qt == "minmax" and meta["bits"] <= 8 and not meta["per_channel"]      # per-tensor scale: the int8 matrix cores
+    want = {"auto": pkg._lib.PATH_I8 if i8_ok else (pkg._lib.PATH_F16X2 if f16_ok else pkg._lib.PATH_F16X3), "f32": pkg._lib.PATH_F32,
             "f16x3": pkg._lib.PATH_F16X3, "u8x2": None}[path]
     if path == "u8x2":
         want = pkg._lib.PATH_U8X2 if meta["bits"] <= 8 else (pkg._lib.PATH_F16X2 if meta["bits"] <= 12 else pkg._lib.PATH_F32)

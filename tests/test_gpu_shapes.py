@@ -86,6 +86,8 @@ def test_linear_shapes_against_oracle(pkg, name, M, K, N, r, bits, qtype, pc):
     assert_close_y(y, ol.forward(x1), f"{name}.y", tol)
     assert_close_y(base, ol.forward(x1, calibration_mode=True), f"{name}.base", tol)
     want = pkg._lib.PATH_F16X2 if (qtype == "minmax" and bits <= 12) else pkg._lib.PATH_F16X3
+    if qtype == "minmax" and bits <= 8 and not pc and K % 4 == 0:
+        want = pkg._lib.PATH_I8                          # per-tensor input scale: the int8 matrix cores
     assert layer._last_path == want
     if want == pkg._lib.PATH_F16X3:                      # the always-valid fp32 operands agree too
         layer.operand_path = pkg._lib.PATH_F32

@@ -132,6 +132,17 @@ def test_operand_path_choice():
     assert layer._choose_path(qx6, None, layer.lora_adapters["6bit"], True, 1) == L.PATH_F32    # pinned but invalid
     layer.operand_path = L.PATH_F32
     assert layer._choose_path(qx6, None, layer.lora_adapters["6bit"], True, 1) == L.PATH_F32
+    # int8 matrix cores: only when the input scale is per tensor and the weights are symmetric minmax <= 8 bit; AUTO takes it
+    qw4 = layer.quantizers_weight["4bit"]
+    layer.operand_path = L.PATH_I8
+    qx4.scale = torch.ones(1, 1, layer.in_features)
+    assert layer._choose_path(qx4, qw4, layer.lora_adapters["4bit"], True, 1) == L.PATH_F16X2     # per-channel: fp16 limbs
+    assert layer._choose_path(qx6, layer.quantizers_weight["6bit"], layer.lora_adapters["6bit"], True, 1) == L.PATH_F16X3
+    qx4.scale = torch.ones(1, 1, 1)
+    assert layer._choose_path(qx4, qw4, layer.lora_adapters["4bit"], True, 1) == L.PATH_I8
+    assert layer._choose_path(qx4, qw4, layer.lora_adapters["4bit"], True, 0) == L.PATH_F32       # calibration forward: raw x
+    layer.operand_path = L.PATH_AUTO
+    assert layer._choose_path(qx4, qw4, layer.lora_adapters["4bit"], True, 1) == L.PATH_I8
 
 
 def test_forward_refuses_cpu_tensors_and_teacher_path_is_plain_linear():

@@ -8,7 +8,7 @@ import llm_qat_on_gpt2_amd as pkg
 from llm_qat_on_gpt2_amd import synthetic as O          # seeded input generator
 
 dev = 'cuda:0'
-PATHN = {1: 'f32', 2: 'f16x2', 3: 'u8x2', 4: 'f16x3'}
+PATHN = {1: 'f32', 2: 'f16x2', 3: 'u8x2', 4: 'f16x3', 5: 'i8'}
 
 
 def build(M, K, N, r, bits, qt, pc, seed=0):

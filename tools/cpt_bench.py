@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import llm_qat_on_gpt2_amd as pkg
 from llm_qat_on_gpt2_amd import synthetic as C          # seeded input generator
 dev = 'cuda:0'
-PATHN = {1: 'f32', 2: 'f16x2', 3: 'u8x2', 4: 'f16x3'}
+PATHN = {1: 'f32', 2: 'f16x2', 3: 'u8x2', 4: 'f16x3', 5: 'i8'}
 
 
 def timeit(fn, n=50):
