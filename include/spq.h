@@ -236,6 +236,14 @@ typedef struct spq_fwd_args {
    * pass's workgroups when that pass is the 16-row kernel (M < 16384) and each workgroup gets <= 8 rows; otherwise the
    * ordinary preparation launch is issued first.  SPQ_FUSE_PREPARE=0 always takes the latter. */
   const struct spq_prepare_args* prepare;
+  /* F16 / I8 operand paths, optional LayerNorm prologue: with ln_weight / ln_bias [K] set, `x` is the INPUT of
+   * the SwitchableLayerNorm that precedes the layer (switchable_batchnorm.py:102-109; models_sp.py:160-171: ln_1 -> c_attn,
+   * ln_2 -> c_fc) and the activation pass normalises each row on the fly -- the same arithmetic, bit for bit, as
+   * spq_layernorm -- so the normalised activation is never written to or read from memory.  Needs K % 64 == 0, K <= 1024,
+   * rank <= 64; SPQ_ERR_UNSUPPORTED otherwise (run spq_layernorm first then). */
+  const float* ln_weight;
+  const float* ln_bias;
+  float ln_eps;
 } spq_fwd_args;
 
 size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path);

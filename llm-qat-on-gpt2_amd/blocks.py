@@ -130,8 +130,10 @@ class SPMLP(nn.Module):
         self.c_proj.set_precision(bits)
         return bits
 
-    def forward(self, hidden_states):
-        hidden_states = self.c_fc(hidden_states, activation='gelu')      # c_fc + self.act in one store where possible
+    def forward(self, hidden_states, pre_norm=None):
+        """``pre_norm``: the LayerNorm whose output the MLP consumes (ln_2); ``hidden_states`` is then its input and c_fc's
+        activation pass applies it (SPLinearWithLoRA.forward)."""
+        hidden_states = self.c_fc(hidden_states, activation='gelu', pre_norm=pre_norm)   # LN + c_fc + GELU: two launches
         return self.c_proj(hidden_states)
 
 
@@ -159,9 +161,9 @@ class SPAttention(nn.Module):
         self.c_proj.set_precision(bits)
         return self.current_bit_width
 
-    def forward(self, hidden_states, attention_mask=None):
+    def forward(self, hidden_states, attention_mask=None, pre_norm=None):
         B, T, C = hidden_states.shape
-        q, k, v = self.c_attn(hidden_states).split(self.n_embd, dim=2)
+        q, k, v = self.c_attn(hidden_states, pre_norm=pre_norm).split(self.n_embd, dim=2)
         q = q.view(B, T, self.n_head, self.head_dim).transpose(1, 2)
         k = k.view(B, T, self.n_head, self.head_dim).transpose(1, 2)
         v = v.view(B, T, self.n_head, self.head_dim).transpose(1, 2)
@@ -201,8 +203,10 @@ class SPBlock(nn.Module):
         return self._forward(hidden_states, attention_mask)
 
     def _forward(self, hidden_states, attention_mask=None):
-        hidden_states = hidden_states + self.attn(self.ln_1(hidden_states), attention_mask)
-        return hidden_states + self.mlp(self.ln_2(hidden_states))
+        # models_sp.py:160-171.  ln_1 / ln_2 are handed to their only consumers (c_attn, c_fc), whose activation pass applies
+        # them on the fly where it can (the normalised tensor is then never stored); same values as calling them here.
+        hidden_states = hidden_states + self.attn(hidden_states, attention_mask, pre_norm=self.ln_1)
+        return hidden_states + self.mlp(hidden_states, pre_norm=self.ln_2)
 
 
 class SPModel(nn.Module):

@@ -144,4 +144,38 @@ __device__ __forceinline__ float wave_max_nan(float v) {
   return v;
 }
 
+
+// SwitchableLayerNorm row statistics (switchable_batchnorm.py:102-109): mean, then the mean of squared deviations as
+// x.var(unbiased=False) defines it, over a row held in registers (NV float4 per lane, element c = (64 i + lane) * 4).
+// Shared by layernorm_kernel and by the activation pass that applies the LayerNorm on the fly, so both produce the same bits.
+// Extra iterations (c >= cols) add nothing: any NV that covers the row gives the same result.
+template <int NV>
+__device__ __forceinline__ void ln_row_stats(const float* __restrict__ xr, int cols, float eps, int lane, float4 (&v)[NV],
+                                             float& mean, float& den) {
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols) { v[i] = *reinterpret_cast<const float4*>(xr + c); sum += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  mean = sum / (float)cols;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < cols) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  den = sqrtf(sq / (float)cols + eps);           // torch.sqrt(var + eps)
+}
+// one normalised element: weight * ((x - mean) / den) + bias, each operation its own rounding (-ffp-contract=off)
+__device__ __forceinline__ float ln_apply(float x, float mean, float den, float w, float b) { return w * ((x - mean) / den) + b; }
+
 }  // namespace spq

@@ -232,7 +232,40 @@ struct XPassArgs {
   float* t_out;                             // optional fp32 [M, r]: the LoRA-down product itself
   int lora_fq;                              // 1: the LoRA-down product consumes FQ(x) (part2 CPTLinear), 0: raw x (part1)
   const float* ascale;                      // device {2^S, 2^-S} for the fp16 limbs of aT (xpass_panel16_kernel); null: f32 MFMA
+  // optional LayerNorm prologue: x is the INPUT of the SwitchableLayerNorm in front of the layer
+  // (switchable_batchnorm.py:102-109); the pass normalises each row on the fly -- weight * ((x - mean) / sqrt(var + eps)) + bias,
+  // bit for bit what spq_layernorm writes -- so the normalised fp32 activation is never stored or re-read.  K <= 1024.
+  const float* ln_w; const float* ln_b; float ln_eps;
 };
+
+// LayerNorm prologue of the panel kernels.  ln_panel_stats: wave w takes rows 4w .. 4w+3 of the workgroup's row block (row in
+// registers, two-pass statistics: ln_row_stats) and leaves {mean, den} per row in `st`.  ln_panel_apply: every thread normalises
+// its own 16-byte slot of each landed chunk in place (the slot the level pass reads), before anything else reads the panel.
+__device__ __forceinline__ void ln_panel_stats(const XPassArgs& a, int m0, int rows, float* st) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * w + i;
+    if (row < rows) {
+      float4 v[4];
+      float mean, den;
+      ln_row_stats<4>(a.x + (int64_t)min(m0 + row, a.M - 1) * a.K, a.K, a.ln_eps, lane, v, mean, den);
+      if (lane == 0) { st[2 * row] = mean; st[2 * row + 1] = den; }
+    }
+  }
+}
+__device__ __forceinline__ void ln_panel_apply(const XPassArgs& a, char* xs, int chunk_stride, int nch, int p0, int q_row, int q_pos,
+                                               int q_kof, const float* st) {
+  const float mean = st[2 * q_row], den = st[2 * q_row + 1];
+  for (int c = 0; c < nch; ++c) {
+    float4* slot = reinterpret_cast<float4*>(xs + c * chunk_stride + q_row * 256 + q_pos * 16);
+    const int k = p0 + c * 64 + q_kof;
+    const float4 wv = *reinterpret_cast<const float4*>(a.ln_w + k), bv = *reinterpret_cast<const float4*>(a.ln_b + k);
+    float4 v = *slot;
+    v.x = ln_apply(v.x, mean, den, wv.x, bv.x); v.y = ln_apply(v.y, mean, den, wv.y, bv.y);
+    v.z = ln_apply(v.z, mean, den, wv.z, bv.z); v.w = ln_apply(v.w, mean, den, wv.w, bv.w);
+    *slot = v;
+  }
+}
 
 // One WAVE per output row (4 rows per workgroup): the row's FQ(W) values stay in registers between the max pass and
 // the limb pass, reductions are 64-lane shuffles, loads are 16 B per lane and stores 8 B per lane.  Needs K % 4 == 0,
@@ -673,7 +706,7 @@ constexpr int XP_AS = 64 * 64 * 4;                         // 16 KB per FQ(A)^T 
 constexpr int XP_NAS = 2;                                  // FQ(A)^T chunk buffers
 constexpr int xp_xs(int ch) { return ch * XR * 64 * 4; }   // x panel image: 96 KB / 32 KB
 constexpr int xp_sx(int ch) { return 2 * ch * 64 * 4; }    // the panel's input scales and zero points
-constexpr int xp_lds(int ch) { return xp_xs(ch) + XP_NAS * XP_AS + xp_sx(ch); }   // 131 KB / 66 KB
+constexpr int xp_lds(int ch) { return xp_xs(ch) + XP_NAS * XP_AS + xp_sx(ch) + 256; }   // 131 KB / 66 KB (+ LayerNorm row statistics)
 constexpr int XP_XS = xp_xs(XP_CHUNKS);
 constexpr int XP_LDS = xp_lds(XP_CHUNKS);
 
@@ -685,9 +718,11 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
   char* xs = xsm;
   char* as = xsm + xp_xs(CH);
   float* sxs = reinterpret_cast<float*>(xsm + xp_xs(CH) + XP_NAS * XP_AS);
+  float* lnst = reinterpret_cast<float*>(xsm + xp_xs(CH) + XP_NAS * XP_AS + xp_sx(CH));
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // 8 waves: two per SIMD, so one's VALU runs under the other's MFMAs
   const int m0 = blockIdx.x * XR;
+  if (a.ln_w) ln_panel_stats(a, m0, XR, lnst);              // visible to every thread after the first panel's barrier
   const float qhi = (float)((1 << (a.bits - 1)) - 1), qlo = -qhi;
   const float pscale = a.limbs ? a.xscale[0] : 1.f;
   const bool with_lora = a.r > 0;
@@ -742,6 +777,7 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
     }
     if (with_lora && p0 == 0) SPQ_STORE_A(0);
     __syncthreads();                                       // vmcnt(0): the panel landed; FQ(A)^T chunk gc is in LDS
+    if (a.ln_w) { ln_panel_apply(a, xs, XR * 256, nch, p0, q_row, q_pos, q_kof, lnst); __syncthreads(); }
     for (int c = 0; c < nch; ++c, ++gc) {
       const int k0 = p0 + c * 64;
       const bool next_a = with_lora && gc + 1 < total_chunks;
@@ -791,7 +827,7 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
 // -------------------------------------------------------------------------------------------------------------------
 constexpr int XR16 = 16, XP16R_CH = 8;
 constexpr int XP16R_XS = XP16R_CH * XR16 * 256;             // 32 KB
-constexpr int XP16R_LDS = XP16R_XS + XP_NAS * XP_AS + 2 * XP16R_CH * 64 * 4;   // + 32 KB + 4 KB
+constexpr int XP16R_LDS = XP16R_XS + XP_NAS * XP_AS + 2 * XP16R_CH * 64 * 4 + 256;   // + 32 KB + 4 KB (+ LayerNorm row statistics)
 // PREP: every workgroup first makes `prep_rows` consecutive rows of the weight-side operands (prep_row_wave: FQ(W), fold sx,
 // FQ(B) column, exponent, limb split) -- the work of prep_f16x2_wave_kernel spread over the activation pass's workgroups, so
 // the per-call re-quantisation of the weights (lora.py:142, :50) costs no launch of its own and no extra round of workgroups.
@@ -802,9 +838,11 @@ __global__ __launch_bounds__(256, 2) void xpass_rows16_kernel(XPassArgs a, PrepA
   char* xs = xsm;
   char* as = xsm + XP16R_XS;
   float* sxs = reinterpret_cast<float*>(xsm + XP16R_XS + XP_NAS * XP_AS);
+  float* lnst = reinterpret_cast<float*>(xsm + XP16R_XS + XP_NAS * XP_AS + 2 * XP16R_CH * 64 * 4);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * XR16;
+  if (a.ln_w) ln_panel_stats(a, m0, XR16, lnst);            // visible to every thread after the first panel's barrier
   const float qhi = (float)((1 << (a.bits - 1)) - 1), qlo = -qhi;
   const float pscale = a.limbs ? a.xscale[0] : 1.f;
   const bool with_lora = a.r > 0;
@@ -880,6 +918,7 @@ __global__ __launch_bounds__(256, 2) void xpass_rows16_kernel(XPassArgs a, PrepA
     }
     if (with_lora && p0 == 0) SPQ_STORE_A(0);
     __syncthreads();                                       // vmcnt(0): the panel landed; FQ(A)^T chunk gc is in LDS
+    if (a.ln_w) { ln_panel_apply(a, xs, XR16 * 256, nch, p0, q_row, q_pos, q_kof, lnst); __syncthreads(); }
     for (int c = 0; c < nch; ++c, ++gc) {
       const int k0 = p0 + c * 64;
       const bool next_a = with_lora && gc + 1 < total_chunks;
@@ -2339,6 +2378,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   x.t_out = (a->r > 0) ? a->t_out : nullptr;
   x.lora_fq = (a->lora_on_fq_input && a->quantize_input) ? 1 : 0;
   x.ascale = a->a_limb_scale;
+  x.ln_w = a->ln_weight; x.ln_b = a->ln_bias; x.ln_eps = a->ln_eps;
   const bool lora_up = a->r > 0 && a->b_prep != nullptr;     // r > 0 without b_prep: LoRA-down only (t_out)
   if (a->path == SPQ_PATH_U8X2 && a->bits > 8) {
     set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 needs an input quantizer of at most 8 bits (got %d)", a->bits);
@@ -2385,6 +2425,13 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   } else if (a->prepare && !do_xpass) {
     set_error("spq_linear_lora_fwd: prepare args go with the activation stage");
     return SPQ_ERR_INVALID;
+  }
+  if (a->ln_weight && do_xpass) {
+    // the LayerNorm prologue lives in the panel kernels (fp32-MFMA LoRA-down), rows of at most 1024 elements
+    if (!a->ln_bias || !panel_ok || a->K > 1024 || (x.ascale && a->r > 0) || !aligned16(a->ln_weight) || !aligned16(a->ln_bias)) {
+      set_error("spq_linear_lora_fwd: the LayerNorm prologue needs K %% 64 == 0, K <= 1024, rank <= 64 and 16-byte aligned operands");
+      return SPQ_ERR_UNSUPPORTED;
+    }
   }
   if (!do_xpass) {
     // the activation pass of this call ran earlier (same arguments, same workspace)

@@ -210,36 +210,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const float* xr = x + row * cols;
   float* orow = out + row * cols;
   float4 v[NV];
-  float sum = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < cols) { v[i] = *reinterpret_cast<const float4*>(xr + c); sum += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-  const float mean = sum / (float)cols;
-  float sq = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (c < cols) {
-      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
-      sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-  const float den = sqrtf(sq / (float)cols + eps);           // torch.sqrt(var + eps)
+  float mean, den;
+  ln_row_stats<NV>(xr, cols, eps, lane, v, mean, den);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < cols) {
       const float4 wv = *reinterpret_cast<const float4*>(w + c), bv = *reinterpret_cast<const float4*>(b + c);
       float4 o;
-      o.x = wv.x * ((v[i].x - mean) / den) + bv.x; o.y = wv.y * ((v[i].y - mean) / den) + bv.y;
-      o.z = wv.z * ((v[i].z - mean) / den) + bv.z; o.w = wv.w * ((v[i].w - mean) / den) + bv.w;
+      o.x = ln_apply(v[i].x, mean, den, wv.x, bv.x); o.y = ln_apply(v[i].y, mean, den, wv.y, bv.y);
+      o.z = ln_apply(v[i].z, mean, den, wv.z, bv.z); o.w = ln_apply(v[i].w, mean, den, wv.w, bv.w);
       *reinterpret_cast<float4*>(orow + c) = o;
     }
   }

@@ -222,6 +222,9 @@ class SPLinearWithLoRA(nn.Module):
         self._last_t = None                       # LoRA-down product of the last training forward (consumed by autograd)
         self._activation_fused = False
         self._last_path = None                    # operand path of the most recent fused forward
+        self.fuse_norm = True                     # apply a preceding SwitchableLayerNorm inside the activation pass (forward(pre_norm=))
+        self._pre_norm = None
+        self._norm_fused = False
 
     # ---- precision switching (lora.py:105-125): attribute flips only ---------------------------------------
     def set_precision(self, bits) -> int:
@@ -248,16 +251,53 @@ class SPLinearWithLoRA(nn.Module):
         self._wq_t = None
 
     # ---- forward (lora.py:127-150) ---------------------------------------------------------------------------
-    def forward(self, x, activation=None):
+    def forward(self, x, activation=None, pre_norm=None):
         """``activation='gelu'`` (not in the reference's signature; used by this package's SPMLP): the exact-erf GELU that
         follows mlp.c_fc (models_sp.py:124-126) is applied to the output -- inside the contraction's store when the fused
-        no-grad path runs, as a separate ``F.gelu`` otherwise."""
+        no-grad path runs, as a separate ``F.gelu`` otherwise.
+
+        ``pre_norm`` (this package's SPBlock): the SwitchableLayerNorm whose output this layer consumes (models_sp.py:160-171:
+        ln_1 -> c_attn, ln_2 -> c_fc); ``x`` is then that LayerNorm's INPUT.  Where the fused no-grad path allows, the
+        normalisation happens inside the activation pass (spq_fwd_args.ln_weight) and the normalised tensor is never stored;
+        otherwise ``pre_norm(x)`` is simply computed first.  Same values either way (the kernels share the arithmetic)."""
         if activation not in (None, 'gelu'):
             raise ValueError(f"unknown activation {activation!r}")
-        y = self._forward(x, activation)
+        self._norm_fused = False
+        if pre_norm is not None:
+            if self._can_fuse_norm(x, pre_norm):
+                self._pre_norm = pre_norm
+            else:
+                x = pre_norm(x)
+        try:
+            y = self._forward(x, activation)
+        finally:
+            self._pre_norm = None
         if activation == 'gelu' and not self._activation_fused:
             y = F.gelu(y)
         return y
+
+    def _can_fuse_norm(self, x, norm) -> bool:
+        """The LayerNorm prologue of the activation pass exists in the panel kernels of the limb / int8 paths: fp32 CUDA input,
+        no gradient, a calibrated symmetric-minmax-or-any input quantizer that is not recording statistics (those need the
+        normalised tensor itself), K % 64 == 0, K <= 1024, rank <= 64."""
+        if not self.fuse_norm or self.current_bits >= 32 or not x.is_cuda or x.dtype != torch.float32:
+            return False
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())
+                                        or any(p.requires_grad for p in norm.parameters())):
+            return False
+        key = f'{self.current_bits}bit'
+        if key not in self.quantizers_input or key not in self.quantizers_weight:
+            return False
+        qx, qw, lora = self.quantizers_input[key], self.quantizers_weight[key], self.lora_adapters[key]
+        if qx.collecting_stats or qw.collecting_stats or not qx.calibrated or qx.num_bits >= 32:
+            return False
+        if lora.enabled and (lora.quantize_A.collecting_stats or lora.quantize_B.collecting_stats or lora.rank > 64):
+            return False
+        K = self.in_features
+        if K % 64 != 0 or K > 1024 or tuple(norm.normalized_shape) != (K,) or x.shape[-1] != K or _LORA_DOWN_F16:
+            return False
+        use_lora = (not self.calibration_mode) and lora.enabled and lora.scaling != 0
+        return self._choose_path(qx, qw, lora, use_lora, 1) in (_lib.PATH_F16X2, _lib.PATH_F16X3, _lib.PATH_I8)
 
     def _forward(self, x, activation=None):
         self._activation_fused = False
@@ -351,6 +391,11 @@ class SPLinearWithLoRA(nn.Module):
             a_limb_scale=_lib.ptr(prep.a_limb_scale) if r else None)
         if prep.pending is not None:
             a.prepare = ctypes.pointer(prep.pending)
+        norm = self._pre_norm
+        if norm is not None:                              # the activation pass normalises the rows itself
+            nw, nb = norm.weights[str(norm.current_precision)], norm.biases[str(norm.current_precision)]
+            a.ln_weight, a.ln_bias, a.ln_eps = nw.data_ptr(), nb.data_ptr(), float(norm.eps)
+            self._norm_fused = True
         if activation == 'gelu' and ((prep.path in (_lib.PATH_F16X2, _lib.PATH_F16X3) and _MFMA16)
                                      or prep.path == _lib.PATH_I8):
             a.epilogue = _lib.EPILOGUE_GELU

@@ -147,3 +147,84 @@ def test_spblock_against_reference_fixture(pkg, name):
         y_explicit = blk(x2)
     same = ((y_explicit - y).abs() <= 1e-5 * y.abs() + 1e-5 * rms).all(dim=-1)
     assert float((~same).float().mean()) <= 0.05
+
+
+def _make_block(pkg, name):
+    meta, t = load_blk(name)
+    bits, r = meta["bits"], meta["r"]
+    cfg = types.SimpleNamespace(n_embd=meta["E"], n_head=meta["H"], n_positions=meta["n_positions"], layer_norm_epsilon=1e-5,
+                                bit_widths=[bits, 32], lora_rank_per_bit={bits: r, 32: 0}, lora_alpha_per_bit={bits: meta["alpha"], 32: 0},
+                                quantizer_per_bit={bits: meta["qtype"], 32: None}, per_channel_quantization=True)
+    blk = pkg.SPBlock(cfg, bit_widths=[bits, 32])
+    with torch.no_grad():
+        for n, p_ in blk.named_parameters():
+            p_.copy_(t[f"param.{n}"])
+    blk = blk.to(DEV).eval()
+    pkg.calibrate_model(blk, bits, [t["x0"].to(DEV), t["x1"].to(DEV)])
+    return blk, t, bits
+
+
+@pytest.mark.parametrize("name", ["block_mm4", "block_mm8"])
+def test_layernorm_inside_the_activation_pass_block(pkg, name):
+    """ln_1 -> c_attn and ln_2 -> c_fc with the LayerNorm applied inside the consumer's activation pass (the
+    normalised tensor is never stored): bit-identical to running the LayerNorm kernel first -- same arithmetic, hence the same
+    integer levels -- on the reference-shaped block."""
+    blk, t, bits = _make_block(pkg, name)
+    lins = [blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc, blk.mlp.c_proj]
+    x2 = t["x2"].to(DEV)
+    with torch.no_grad():
+        for lin in lins:
+            lin.fuse_norm = False
+        y_sep = blk(x2)
+        assert not blk.attn.c_attn._norm_fused and not blk.mlp.c_fc._norm_fused
+        for lin in lins:
+            lin.fuse_norm = True
+        y_fused = blk(x2)
+        assert blk.attn.c_attn._norm_fused and blk.mlp.c_fc._norm_fused
+        assert torch.equal(y_fused, y_sep)
+        # calibration forwards need the normalised tensor itself (statistics): they must not take the prologue
+        q = blk.attn.c_attn.quantizers_input[f"{bits}bit"]
+        q.start_calibration()
+        blk(x2)
+        assert not blk.attn.c_attn._norm_fused
+        q.finish_calibration()
+        # 32-bit teacher path: plain LayerNorm + F.linear
+        blk.set_precision(32)
+        assert_close_y(blk(x2), t["y32"], f"{name}.y32", 1e-5)
+
+
+@pytest.mark.parametrize("M,K,N,r,bits,qtype,pc", [
+    (8192, 768, 2304, 64, 4, "minmax", True),       # ln_1 -> c_attn of GPT-2-small, 16-row activation kernel
+    (32768, 768, 3072, 64, 4, "minmax", True),      # ln_2 -> c_fc at BASELINE config 3's 32 x 1024 tokens: 32-row panel kernel
+    (4096, 1024, 4096, 64, 6, "log", True),         # GPT-2-medium dims, log quantizer: two-limb activations
+    (4096, 768, 768, 16, 8, "minmax", False),       # per-tensor scale: int8 operand path
+    (1000, 256, 512, 0, 4, "minmax", True),         # ragged M, no LoRA
+])
+def test_layernorm_inside_the_activation_pass_shapes(pkg, M, K, N, r, bits, qtype, pc):
+    from llm_qat_on_gpt2_amd import synthetic as S
+    W, bias, A, B, x0, x1 = S.make_workload(M, K, N, max(r, 1), seed=K + bits, batch=1)
+    ln = pkg.SwitchableLayerNorm(K, precision_levels=[bits, 32], eps=1e-5)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        ln.weights[str(bits)].copy_(torch.randn(K, generator=g) * 0.2 + 1.0); ln.biases[str(bits)].copy_(torch.randn(K, generator=g) * 0.1)
+    ln = ln.to(DEV); ln.set_precision(bits)
+    layer = pkg.SPLinearWithLoRA(K, N, [bits, 32], {bits: r, 32: 0}, {bits: max(r, 1), 32: 0}, {bits: qtype, 32: None}, per_channel=pc)
+    key = f"{bits}bit"
+    with torch.no_grad():
+        layer.linear.weight.copy_(W); layer.linear.bias.copy_(bias)
+        if r:
+            layer.lora_adapters[key].lora_A.copy_(A); layer.lora_adapters[key].lora_B.copy_(B)
+    layer = layer.to(DEV).eval(); layer.set_precision(bits)
+    xin = (x1 * 1.7 + 0.3).to(DEV)
+    xin[:, 3] += 25.0                                                   # an outlier channel, as GPT-2 residual streams have
+    with torch.no_grad():
+        h = ln(xin)
+        pkg.calibrate_layer(layer, bits, [h, ln((x0 * 1.7 + 0.3).to(DEV))])
+        y_sep = layer(h)
+        y_fused = layer(xin, pre_norm=ln)
+        assert layer._norm_fused
+        assert torch.equal(y_fused, y_sep), f"max abs diff {float((y_fused - y_sep).abs().max()):.3e}"
+        y_gelu = layer(xin, activation="gelu", pre_norm=ln)
+        assert torch.equal(y_gelu, layer(h, activation="gelu"))
+        layer.fuse_norm = False
+        assert torch.equal(layer(xin, pre_norm=ln), y_sep) and not layer._norm_fused

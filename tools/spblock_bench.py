@@ -36,7 +36,13 @@ def timeit(fn, n=20):
 
 lin_flop = M * (2 * E * 12 * E + 2 * r * (2 * E + 3 * E + 2 * E + 5 * E + 5 * E - 2 * E))   # 2MKN + 2Mr(K+N) over the four linears
 lin_flop = sum(2 * M * (K * N + K * r + r * N) for K, N in ((E, 3 * E), (E, E), (E, 4 * E), (4 * E, E)))
+lins = [blk.attn.c_attn, blk.attn.c_proj, blk.mlp.c_fc, blk.mlp.c_proj]
 with torch.no_grad():
+    for l in lins: l.fuse_norm = False
+    t_blk_sep = timeit(lambda: blk(x))                     # LayerNorm as its own kernel in front of c_attn / c_fc
+    t_pairs_sep = timeit(lambda: blk.attn.c_attn(blk.ln_1(x))) + timeit(lambda: blk.mlp.c_fc(blk.ln_2(x), activation='gelu'))
+    for l in lins: l.fuse_norm = True
+    t_pairs_fused = timeit(lambda: blk.attn.c_attn(x, pre_norm=blk.ln_1)) + timeit(lambda: blk.mlp.c_fc(x, activation='gelu', pre_norm=blk.ln_2))
     t_blk = timeit(lambda: blk(x))
     h1 = blk.ln_1(x)
     t_ln = timeit(lambda: blk.ln_1(x))
@@ -44,4 +50,6 @@ with torch.no_grad():
     t_attn = timeit(lambda: blk.attn(h1))
 print(f'SPBlock {args.batch} x {args.seq} tokens, E={E}, {bits}-bit minmax + LoRA r=64: block forward {t_blk:.3f} ms '
       f'({lin_flop / t_blk / 1e9:.0f} TFLOP/s counting the four linears only); of which: 4 linears + GELU {t_lin:.3f} ms '
-      f'({lin_flop / t_lin / 1e9:.0f} TFLOP/s), 2 LayerNorms {2 * t_ln:.3f} ms, attention incl. its two linears {t_attn:.3f} ms')
+      f'({lin_flop / t_lin / 1e9:.0f} TFLOP/s), 2 LayerNorms {2 * t_ln:.3f} ms, attention incl. its two linears {t_attn:.3f} ms; '
+      f'LayerNorm inside the activation pass (default) vs as its own kernel: block {t_blk:.3f} vs {t_blk_sep:.3f} ms, '
+      f'[ln_1 -> c_attn] + [ln_2 -> c_fc + GELU] {t_pairs_fused:.3f} vs {t_pairs_sep:.3f} ms')
