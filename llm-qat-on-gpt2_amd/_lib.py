@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspq.so")
+LIB_PATH = os.environ.get("SPQ_LIB") or os.path.join(_HERE, "libspq.so")   # SPQ_LIB: an alternative build (kernel tuning)
 
 MINMAX, LOG = 0, 1
 STAGE_ALL, STAGE_ACTIVATIONS, STAGE_CONTRACTION = 0, 1, 2

@@ -825,14 +825,17 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
 // latency chains (the pass costs half as much per row once a CU holds two workgroups: 21 -> 10 us per 8192 x 768 rows).
 // LoRA-down on v_mfma_f32_16x16x4_f32: wave w owns k in [16w, 16w+16) of a chunk, lane quarter q its 4 contiguous k.
 // -------------------------------------------------------------------------------------------------------------------
-constexpr int XR16 = 16, XP16R_CH = 8;
+#ifndef SPQ_XP16R_CH
+#define SPQ_XP16R_CH 8
+#endif
+constexpr int XR16 = 16, XP16R_CH = SPQ_XP16R_CH;
 constexpr int XP16R_XS = XP16R_CH * XR16 * 256;             // 32 KB
 constexpr int XP16R_LDS = XP16R_XS + XP_NAS * XP_AS + 2 * XP16R_CH * 64 * 4 + 256;   // + 32 KB + 4 KB (+ LayerNorm row statistics)
 // PREP: every workgroup first makes `prep_rows` consecutive rows of the weight-side operands (prep_row_wave: FQ(W), fold sx,
 // FQ(B) column, exponent, limb split) -- the work of prep_f16x2_wave_kernel spread over the activation pass's workgroups, so
 // the per-call re-quantisation of the weights (lora.py:142, :50) costs no launch of its own and no extra round of workgroups.
 template <int PREP>   // 0: no weight rows; 1: fp16 limb rows; 2: int8 level rows (SPQ_PATH_I8)
-__global__ __launch_bounds__(256, 2) void xpass_rows16_kernel(XPassArgs a, PrepArgs pa, int prep_rows) {
+__global__ __launch_bounds__(256, SPQ_XP16R_CH <= 4 ? 3 : 2) void xpass_rows16_kernel(XPassArgs a, PrepArgs pa, int prep_rows) {
   extern __shared__ __attribute__((aligned(16))) char xsm[];
   constexpr int CH = XP16R_CH;
   char* xs = xsm;
@@ -1686,6 +1689,9 @@ constexpr int T128_STAGE = T128_STAGE_A + 2 * STAGE_B;     // 48 KB
 #ifndef T128_WGS
 #define T128_WGS 3
 #endif
+#ifndef T128_DIAG      // tools/gemm_bench only (the library builds 0): 1 = no copies after a tile's first stage, 2 = no MFMAs /
+#define T128_DIAG 0    // fragment reads, 4 = no epilogue stores
+#endif
 constexpr bool T128_DEFER = T128_WGS == 3;
 constexpr int T128_LDS = T128_DEFER ? T128_STAGE : T128_STAGE + 4 * EPI_WAVE;
 #ifndef T128_GROUP_M
@@ -1725,6 +1731,7 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
 #pragma unroll
   for (int i = 0; i < 4; ++i) { pc_row[i] = (4 * w + i) * 8 + prow; pc_col[i] = swz(pc_row[i], pchunk) * 8; }
   auto issue = [&](int t, int tbm, int tbn) {
+    if ((T128_DIAG & 1) && t != 0) return;
     const _Float16 *A, *Bh, *Bl; int lda, ldb, k0; bool two;
     if (t < nl) {
       const int which = t & 1;
@@ -1776,9 +1783,11 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
   auto stage = [&](bool two, bool have_next, int nt, int nbm, int nbn) {
     __syncthreads();                                         // vmcnt(0) + barrier: the stage has landed
     Frags f0, f1;
-    load_frags(f0, 0, two);
-    load_frags(f1, 1, two); mfma_block(f0, two);
-    mfma_block(f1, two);
+    if (!(T128_DIAG & 2)) {
+      load_frags(f0, 0, two);
+      load_frags(f1, 1, two); mfma_block(f0, two);
+      mfma_block(f1, two);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // my fragment reads are complete (and may not sink below)
     __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave has read its fragments
     if (have_next) issue(nt, nbm, nbn);
@@ -1862,7 +1871,8 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
             o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
             if (EPI == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
             float* dst = g.y + (int64_t)m * g.N + n;
-            if (interior) *reinterpret_cast<float4*>(dst) = o;
+            if (T128_DIAG & 4) { if (o.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }
+            else if (interior) *reinterpret_cast<float4*>(dst) = o;
             else if (n_ok && m < g.M) *reinterpret_cast<float4*>(dst) = o;
           }
         }
