@@ -117,6 +117,30 @@ def _time_forwards(fn, budget_s, min_n, max_n):
     return times
 
 
+def _cpu_share():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each job a share
+    of its 256 logical CPUs; torch's default of one thread per physical core then oversubscribes it several times over)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline_and_parity(weights, calib, x, y_gpu, x_levels_gpu, w_levels_gpu, budget_s=10.0):
     """The CPU leg: the oracle -- torch CPU ops in the reference's op order, bit-identical to the imported
     reference on the golden fixtures -- (i) timed on this host's cores at all threads and at one thread on the very tensors the
@@ -132,12 +156,15 @@ def cpu_baseline_and_parity(weights, calib, x, y_gpu, x_levels_gpu, w_levels_gpu
     with torch.no_grad():
         y_ref = layer.forward(x)
         layer.forward(x)
-        n_all = torch.get_num_threads()
+        n_default = torch.get_num_threads()
+        n_all = max(1, min(n_default, _cpu_share()))
+        torch.set_num_threads(n_all)
+        layer.forward(x)
         t_all = _time_forwards(lambda: layer.forward(x), budget_s, 5, 60)
         torch.set_num_threads(1)
         layer.forward(x)
         t_one = _time_forwards(lambda: layer.forward(x), budget_s, 2, 5)
-        torch.set_num_threads(n_all)
+        torch.set_num_threads(n_default)
         # parity gate: SURVEY.md §8d -- levels exact, |dy| <= 1e-5 |y_ref| + 1e-5 rms(y_ref)
         yd, yr = y_gpu.double(), y_ref.double().reshape(y_gpu.shape)
         rms = float(yr.pow(2).mean().sqrt())
@@ -155,7 +182,7 @@ def cpu_baseline_and_parity(weights, calib, x, y_gpu, x_levels_gpu, w_levels_gpu
     med1 = t_one[len(t_one) // 2]
     base = {"value": round(FLOP_PER_STEP / med / 1e9, 2), "unit": "GFLOP/s", "cores": n_all, "kind": "port",
             "sample": f"{len(t_all)} full forwards of the same workload (M={M_TOKENS}), median {med * 1e3:.1f} ms, "
-                      f"min {t_all[0] * 1e3:.1f} ms; host cpu_count={os.cpu_count()} [{model}]",
+                      f"min {t_all[0] * 1e3:.1f} ms; host cpu_count={os.cpu_count()}, usable share {_cpu_share()} [{model}]",
             "min_ms": round(t_all[0] * 1e3, 1), "median_ms": round(med * 1e3, 1),
             "one_thread": {"value": round(FLOP_PER_STEP / med1 / 1e9, 2), "unit": "GFLOP/s", "cores": 1,
                            "sample": f"{len(t_one)} full forwards, median {med1 * 1e3:.0f} ms, min {t_one[0] * 1e3:.0f} ms"}}
