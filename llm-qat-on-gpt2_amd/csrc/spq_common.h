@@ -42,6 +42,21 @@ __device__ __forceinline__ float minmax_level(float x, float scale, float zp, fl
   float q = SYM ? rintf(x / scale) : rintf(x / scale + zp);
   return clampf(q, qlo, qhi);
 }
+// The same level (symmetric form) without the IEEE division, for the streaming activation pass where the division's ~10 VALU
+// instructions per element were the kernel's issue bound.  q = x * rs with rs = v_rcp_f32(scale) (1 ulp), r = rint(q).
+//   |q - x/s| <= (2^-23 + 2^-24) |x/s| and |fl(x/s) - x/s| <= 2^-24 |x/s|, so q and the reference's quotient differ by less than
+//   2^-22 |q|.  rint of the two can differ only if a tie k + 1/2 lies within that distance of q, i.e. only if
+//   |q - r| + 2^-21 |q| >= 1/2 (|q - r| is exact; the test has a 2x margin over the bound and over its own rounding).
+// `unsafe` is raised then -- and for NaN / Inf (x or rs: a zero, subnormal or NaN scale) since the comparison is written to fail
+// on NaN -- and the caller recomputes the element with minmax_level<true>.  A scale above 2^126, whose reciprocal is subnormal,
+// is the caller's to exclude (one compare per scale, not per element).  Returns r unclamped.
+__device__ __forceinline__ float minmax_level_fast(float x, float rs, bool& unsafe) {
+  const float q = x * rs;
+  const float r = rintf(q);
+  const float t = __builtin_fmaf(fabsf(q), 0x1p-21f, fabsf(q - r));
+  unsafe |= !(t < 0.5f);
+  return r;
+}
 // :16 / :20
 template <bool SYM>
 __device__ __forceinline__ float minmax_dequant(float q, float scale, float zp) {

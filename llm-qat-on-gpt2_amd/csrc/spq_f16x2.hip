@@ -831,9 +831,54 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
 constexpr int XR16 = 16, XP16R_CH = SPQ_XP16R_CH;
 constexpr int XP16R_XS = XP16R_CH * XR16 * 256;             // 32 KB
 constexpr int XP16R_LDS = XP16R_XS + XP_NAS * XP_AS + 2 * XP16R_CH * 64 * 4 + 256;   // + 32 KB + 4 KB (+ LayerNorm row statistics)
+// finish of the 16-row kernels: sum the 4 per-wave k-partials (fixed order), per-row power-of-two scale, two fp16 limbs (+ t_out).
+// red: [4][ROWS][64] floats (16 / 32 KB) of LDS that nothing else is using.
+template <int ROWS = XR16>          // ROWS = 32: waves 4..7 hold rows 16..31 (wave = 4 * row group + k-slice)
+__device__ __forceinline__ void xpass16_finish(const XPassArgs& a, const f32x4 (&acc)[4], float* red, int m0, int tid) {
+  const int lane = tid & 63, w = (tid >> 6) & 3, rg = tid >> 8, l15 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(w * ROWS + rg * 16 + 4 * q4 + e) * 64 + t * 16 + l15] = acc[t][e];   // C/D: col = lane&15, row = 4 (lane>>4) + e
+  __syncthreads();
+  const int row = tid >> 4, c0 = (tid & 15) * 4;
+  float tv[4];
+  float rmax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float s01 = red[(0 * ROWS + row) * 64 + c0 + j] + red[(1 * ROWS + row) * 64 + c0 + j];
+    const float s23 = red[(2 * ROWS + row) * 64 + c0 + j] + red[(3 * ROWS + row) * 64 + c0 + j];
+    tv[j] = s01 + s23;
+    rmax = fmaxf(rmax, fabsf(tv[j]));
+  }
+  rmax = fmaxf(rmax, __shfl_xor(rmax, 1, 64)); rmax = fmaxf(rmax, __shfl_xor(rmax, 2, 64));
+  rmax = fmaxf(rmax, __shfl_xor(rmax, 4, 64)); rmax = fmaxf(rmax, __shfl_xor(rmax, 8, 64));
+  const float p = pow2_scale_for(rmax);
+  const int m = m0 + row;
+  if (m < a.M) {
+    if ((tid & 15) == 0) a.rowinv[m] = 1.0f / p;
+    union { _Float16 hh[4]; uint2 u; } hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2(tv[j] * p, hi.hh[j], lo.hh[j]);
+    *reinterpret_cast<uint2*>(a.thi + (int64_t)m * a.Rp + c0) = hi.u;
+    *reinterpret_cast<uint2*>(a.tlo + (int64_t)m * a.Rp + c0) = lo.u;
+    if (a.t_out) {
+      float* to = a.t_out + (int64_t)m * a.r + c0;
+      if ((a.r & 3) == 0 && c0 + 4 <= a.r) *reinterpret_cast<float4*>(to) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (c0 + j < a.r) to[j] = tv[j];
+      }
+    }
+  }
+}
+
 // PREP: every workgroup first makes `prep_rows` consecutive rows of the weight-side operands (prep_row_wave: FQ(W), fold sx,
 // FQ(B) column, exponent, limb split) -- the work of prep_f16x2_wave_kernel spread over the activation pass's workgroups, so
 // the per-call re-quantisation of the weights (lora.py:142, :50) costs no launch of its own and no extra round of workgroups.
+#ifndef SPQ_XP_DIAG    // tools/xpass_probe.py only (the library builds 0): 1 = no FQ(A)^T loads / LDS stores after the first chunk,
+#define SPQ_XP_DIAG 0  // 2 = no MFMAs, 4 = no level stores, 8 = no x copies after the first chunk, 16 = no per-chunk barrier
+#endif
 template <int PREP>   // 0: no weight rows; 1: fp16 limb rows; 2: int8 level rows (SPQ_PATH_I8)
 __global__ __launch_bounds__(256, SPQ_XP16R_CH <= 4 ? 3 : 2) void xpass_rows16_kernel(XPassArgs a, PrepArgs pa, int prep_rows) {
   extern __shared__ __attribute__((aligned(16))) char xsm[];
@@ -893,7 +938,8 @@ __global__ __launch_bounds__(256, SPQ_XP16R_CH <= 4 ? 3 : 2) void xpass_rows16_k
   if (with_lora) SPQ_LOAD_A(0);
   for (int p0 = 0; p0 < a.K; p0 += CH * 64) {
     const int nch = min(CH, (a.K - p0) / 64);
-    for (int c = 0; c < nch; ++c) glds16(x_src + p0 + c * 64, xs + c * (XR16 * 256) + w * 1024);
+    for (int c = 0; c < nch; ++c)
+      if (!(SPQ_XP_DIAG & 8) || (p0 == 0 && c == 0)) glds16(x_src + p0 + c * 64, xs + c * (XR16 * 256) + w * 1024);
     if (PREP && p0 == 0) {
       // weight rows of this workgroup, while the first panel's copies are in flight (their latency and the rows' load latency
       // overlap).  The rows' LoRA-B columns B[j][n0 .. n0+nrows) are short contiguous runs: staged [row][j] in LDS (the second
@@ -924,9 +970,9 @@ __global__ __launch_bounds__(256, SPQ_XP16R_CH <= 4 ? 3 : 2) void xpass_rows16_k
     if (a.ln_w) { ln_panel_apply(a, xs, XR16 * 256, nch, p0, q_row, q_pos, q_kof, lnst); __syncthreads(); }
     for (int c = 0; c < nch; ++c, ++gc) {
       const int k0 = p0 + c * 64;
-      const bool next_a = with_lora && gc + 1 < total_chunks;
+      const bool next_a = with_lora && gc + 1 < total_chunks && !(SPQ_XP_DIAG & 1);
       if (next_a) SPQ_LOAD_A((gc + 1) * 64);
-      {
+      if (!(SPQ_XP_DIAG & 4) || a.M == 12345) {
         const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR16 * 256) + q_row * 256 + q_pos * 16);
         const float4 sc = *reinterpret_cast<const float4*>(sxs + c * 64 + q_kof);
         const float4 zp = *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + q_kof);
@@ -942,6 +988,7 @@ __global__ __launch_bounds__(256, SPQ_XP16R_CH <= 4 ? 3 : 2) void xpass_rows16_k
         for (int t = 0; t < 4; ++t) {
           const int rb = t * 16 + l15;
           const float4 bv = *reinterpret_cast<const float4*>(as + (gc & 1) * XP_AS + rb * 256 + ((pa ^ (rb & 15)) << 4));
+          if (SPQ_XP_DIAG & 2) { acc[t][0] += av.x + bv.x; continue; }
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[t], 0, 0, 0);
@@ -949,52 +996,181 @@ __global__ __launch_bounds__(256, SPQ_XP16R_CH <= 4 ? 3 : 2) void xpass_rows16_k
         }
         if (next_a) SPQ_STORE_A((gc + 1) & 1);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      if (!(SPQ_XP_DIAG & 16)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
     }
     __syncthreads();
   }
 #undef SPQ_LOAD_A
 #undef SPQ_STORE_A
   if (!with_lora) return;
-  // ---- finish: sum the 4 per-wave k-partials (fixed order), per-row power-of-two scale, two fp16 limbs (+ t_out)
-  float* red = reinterpret_cast<float*>(xsm);              // [4][16][64] floats = 16 KB, panel images are free
+  xpass16_finish(a, acc, reinterpret_cast<float*>(xsm), m0, tid);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// Streaming form of the pass for the common case: symmetric min-max levels (fp16 / bytes), LoRA-down on the raw rows, no weight
+// rows.  The panel kernels above alternate "copy a panel" and "work on it", and their parts add up (measured with SPQ_XP_DIAG at
+// 8192 x 768: copies 4.4 + FQ(A)^T 3.5 + fp32 MFMAs 5 + level pass 9 of 21 us, nothing overlaps).  Here every 64-column chunk --
+// the ROWS x 64 piece of x, the 64 x 64 piece of FQ(A)^T (16 KB) and the chunk's 64 scales (+ LayerNorm weight / bias) -- is an
+// LDS-DMA stage of a three-slot ring, issued two chunks ahead: one counted s_waitcnt + one barrier per chunk, no register
+// staging, no LDS writes in the loop, and the level pass runs in the shadow of the chunk's MFMAs.
+//   ROWS = 32 (512 threads: waves 0..3 rows 0..15, waves 4..7 rows 16..31, both halves read the same FQ(A)^T stage) when that
+//   still gives every CU a workgroup: FQ(A)^T is re-read once per workgroup through L2 (M/ROWS x 4 r K bytes: 100 MB at
+//   8192 x 768 with 16 rows against 25 MB of x) and that traffic is what bounds the 16-row form.
+//   vmcnt accounting (gfx9: one in-order counter for loads AND stores): a wave issues CP = 6 (16 rows) or 4 (32 rows) copies
+//   per chunk and one level store.  At the top of chunk c the operations younger than chunk c's copies are {store c-2, CP copies
+//   of c+1, store c-1}: s_waitcnt vmcnt(CP + 2).  (Waiting for vmcnt(CP) instead made every chunk wait for the write
+//   acknowledgement of the level store issued just before it: 4 of the pass's 16 us.)
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int XS_A = 64 * 256, XS_AUX = 1024;               // FQ(A)^T stage; {scales, LayerNorm weight, bias, (unused)} x 256 B
+constexpr int xs_slot(int rows) { return rows * 256 + XS_A + XS_AUX; }
+constexpr int xs_lds(int rows) { return 3 * xs_slot(rows) + 256; }            // 63.25 KB / 75.25 KB: two workgroups per CU
+typedef _Float16 xs_h8 __attribute__((ext_vector_type(8)));
+// read through the fp16 vector type: hipcc drains the copies in flight (s_waitcnt vmcnt(0)) in front of a float-typed LDS read
+// that follows an LDS-DMA, but not in front of a half-typed one
+__device__ __forceinline__ f32x4 xs_ld16(const char* p) { return __builtin_bit_cast(f32x4, *reinterpret_cast<const xs_h8*>(p)); }
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {   // 4 B per lane: 256 B per instruction
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
+// LN: the LayerNorm prologue (XPassArgs::ln_w): row statistics while the first two chunks are in flight, then every thread
+// normalises its own 16-byte slot of a landed chunk in place (one more barrier per chunk) and keeps it for its level pass.
+#if SPQ_XP_DIAG & 128   // in-kernel stamps (s_memtime) of the loop's segments, summed per wave: tools/xpass_probe.py --stamps
+__device__ unsigned long long g_xp_stamps[2048 * 8 * 4];
+#define SPQ_XP_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define SPQ_XP_STAMP(var) const unsigned long long var = 0
+#endif
+template <int ROWS, int A8, bool LN>   // A8 0: fp16 levels; 1: bytes q + 128; 2: int8 q
+__global__ __launch_bounds__(ROWS * 16, 2) void xpass_stream_kernel(XPassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char xsm[];
+  constexpr int NW = ROWS / 4, SLOT = xs_slot(ROWS), XS_X = ROWS * 256, APW = 16 / NW;   // waves; FQ(A)^T pieces per wave
+  float* lnst = reinterpret_cast<float*>(xsm + 3 * SLOT);   // LN only: {mean, den} per row
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ws = w & 3, rg = w >> 2;                        // k-slice of a chunk; 16-row group
+  const int m0 = blockIdx.x * ROWS;
+  const float qhi = (float)((1 << (a.bits - 1)) - 1), qlo = -qhi;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int nck = (SPQ_XP_DIAG & 32) ? 2 : a.K / 64;
+  const int prow = 4 * w + q4;                              // == tid >> 4: my row of the x chunk, my row (+ 4 NW i) of FQ(A)^T
+  const int kof = (l15 ^ (prow & 15)) << 2;                 // LDS slot l15 of row prow holds source columns kof .. kof + 3
+
+  const float* x_src = a.x + (int64_t)min(m0 + prow, a.M - 1) * a.K + kof;
+  const float* a_src = a.aT + (int64_t)prow * a.K + kof;
+  const int64_t a_step = (int64_t)4 * NW * a.K;
+  // the chunk's constants: wave 0 brings the 64 scales, wave 1 / 2 the LayerNorm weight / bias, the others a dummy line
+  const int auxw = ws < 3 && rg == 0 ? ws : 3;
+  const float* aux_src = (auxw == 0 && a.x_pc) ? a.sx + lane : (LN && auxw == 1) ? a.ln_w + lane : (LN && auxw == 2) ? a.ln_b + lane : nullptr;
+  auto issue = [&](int c, int slot) {
+    char* s = xsm + slot * SLOT;
+    if (!(SPQ_XP_DIAG & 8) || c < 2) glds16(x_src + c * 64, s + w * 1024); else glds4(x_src, s + XS_X + XS_A + 768);
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < APW; ++i)
+      if (!(SPQ_XP_DIAG & 1) || c < 2) glds16(a_src + i * a_step + c * 64, s + XS_X + (NW * i + w) * 1024); else glds4(x_src, s + XS_X + XS_A + 768);
+    glds4(aux_src ? aux_src + c * 64 : x_src, s + XS_X + XS_A + auxw * 256);
+  };
+  f32x4 acc[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[(w * XR16 + 4 * q4 + e) * 64 + t * 16 + l15] = acc[t][e];   // C/D: col = lane&15, row = 4 (lane>>4) + e
-  __syncthreads();
-  const int row = tid >> 4, c0 = (tid & 15) * 4;
-  float tv[4];
-  float rmax = 0.f;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float s01 = red[(0 * XR16 + row) * 64 + c0 + j] + red[(1 * XR16 + row) * 64 + c0 + j];
-    const float s23 = red[(2 * XR16 + row) * 64 + c0 + j] + red[(3 * XR16 + row) * 64 + c0 + j];
-    tv[j] = s01 + s23;
-    rmax = fmaxf(rmax, fabsf(tv[j]));
-  }
-  rmax = fmaxf(rmax, __shfl_xor(rmax, 1, 64)); rmax = fmaxf(rmax, __shfl_xor(rmax, 2, 64));
-  rmax = fmaxf(rmax, __shfl_xor(rmax, 4, 64)); rmax = fmaxf(rmax, __shfl_xor(rmax, 8, 64));
-  const float p = pow2_scale_for(rmax);
-  const int m = m0 + row;
-  if (m < a.M) {
-    if ((tid & 15) == 0) a.rowinv[m] = 1.0f / p;
-    union { _Float16 hh[4]; uint2 u; } hi, lo;
+    for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+  const float s_pt = a.x_pc ? 0.f : a.sx[0];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the scalar's load is out of the count
+  issue(0, 0);
+  if (nck > 1) issue(1, 1);
+  if (LN) ln_panel_stats(a, m0, ROWS, lnst);                // its loads drain the count: chunks 0 and 1 land with them
+  const int64_t q_dst = (int64_t)min(m0 + prow, a.M - 1) * a.Kp + kof;
+  const int pa = 4 * ws + q4;                               // 16-B source chunk of this lane's MFMA operands: k = 16 ws + 4 q4 ..
+  int slot = 0;
+  unsigned long long st_wait = 0, st_bar = 0, st_body = 0;
+  SPQ_XP_STAMP(t_begin);
+  for (int c = 0; c < nck; ++c) {
+    SPQ_XP_STAMP(t0);
+    // chunk c's copies are done once only the younger operations remain: {store c-2, CP copies of c+1, store c-1}
+    if (c + 1 < nck && c >= 2) {
+      if (APW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (c + 1 < nck) {
+      if (APW == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else if (c >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SPQ_XP_STAMP(t1);
+    __builtin_amdgcn_s_barrier();                           // chunk c is in LDS; every wave is done with chunk c - 1
+    asm volatile("" ::: "memory");
+    SPQ_XP_STAMP(t2);
+    if (c + 2 < nck) issue(c + 2, slot == 0 ? 2 : slot - 1);
+    SPQ_XP_STAMP(t2a);
+    char* xs = xsm + slot * SLOT;
+    const char* as = xs + XS_X;
+    const char* aux = as + XS_A;
+    f32x4 v;
+    if (LN) {
+      const float mean = lnst[2 * prow], den = lnst[2 * prow + 1];
+      v = xs_ld16(xs + prow * 256 + l15 * 16);
+      const f32x4 wv = xs_ld16(aux + 256 + kof * 4), bb = xs_ld16(aux + 512 + kof * 4);
+      v.x = ln_apply(v.x, mean, den, wv.x, bb.x); v.y = ln_apply(v.y, mean, den, wv.y, bb.y);
+      v.z = ln_apply(v.z, mean, den, wv.z, bb.z); v.w = ln_apply(v.w, mean, den, wv.w, bb.w);
+      *reinterpret_cast<xs_h8*>(xs + prow * 256 + l15 * 16) = __builtin_bit_cast(xs_h8, v);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // the chunk is normalised for every reader
+      asm volatile("" ::: "memory");
+    }
+    // One scheduling region: the chunk's LDS reads, then its 16 fp32 MFMAs with the level arithmetic between them.  Stamped
+    // (SPQ_XP_DIAG=128, cycles per chunk and wave at 8192 x 768): copies' issue 230-460, barrier 80-590, the rest 1400-1660 --
+    // of which the MFMAs alone are 750 (two waves share a SIMD's pipe) and the level pass alone 715.  Moving the level pass a
+    // chunk later (on registers) or running the two row groups in opposite phase order did not shorten the chunk.
+    const f32x4 av = xs_ld16(xs + (rg * 16 + l15) * 256 + ((pa ^ l15) << 4));
+    f32x4 bv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) split2(tv[j] * p, hi.hh[j], lo.hh[j]);
-    *reinterpret_cast<uint2*>(a.thi + (int64_t)m * a.Rp + c0) = hi.u;
-    *reinterpret_cast<uint2*>(a.tlo + (int64_t)m * a.Rp + c0) = lo.u;
-    if (a.t_out) {
-      float* to = a.t_out + (int64_t)m * a.r + c0;
-      if ((a.r & 3) == 0 && c0 + 4 <= a.r) *reinterpret_cast<float4*>(to) = make_float4(tv[0], tv[1], tv[2], tv[3]);
-      else {
+    for (int t = 0; t < 4; ++t) bv[t] = xs_ld16(as + (t * 16 + l15) * 256 + ((pa ^ l15) << 4));
+    if (!LN) v = xs_ld16(xs + prow * 256 + l15 * 16);
+    f32x4 sc = xs_ld16(aux + kof * 4);
+    if (!a.x_pc) { sc.x = s_pt; sc.y = s_pt; sc.z = s_pt; sc.w = s_pt; }
+    float q[4];
+    // levels by reciprocal multiply (minmax_level_fast); a lane whose quotient sits on a rounding tie sends its wave through
+    // the IEEE division below (about one wave-chunk in 500 on Gaussian rows)
+    bool unsafe = !(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])) < 0x1p100f);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (c0 + j < a.r) to[j] = tv[j];
-      }
+    for (int e = 0; e < 4; ++e) {
+      if (!(SPQ_XP_DIAG & 2)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[t][e], acc[t], 0, 0, 0);
+      } else acc[e][0] += av[e] + bv[e][e];
+      q[e] = (SPQ_XP_DIAG & 4) ? 0.f : fminf(fmaxf(minmax_level_fast(v[e], __builtin_amdgcn_rcpf(sc[e]), unsafe), qlo), qhi);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, LN ? 6 : 7, 0);   // every LDS read of the chunk up front
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    // VALU instructions in its shadow
+    }
+    if (!(SPQ_XP_DIAG & 4) && __builtin_amdgcn_ballot_w64(unsafe) != 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[e] = minmax_level<true>(v[e], sc[e], 0.f, qlo, qhi);
+    }
+    if ((!(SPQ_XP_DIAG & 4) && !(SPQ_XP_DIAG & 64)) || a.M == 12345 || ((SPQ_XP_DIAG & 64) && q[0] + q[1] + q[2] + q[3] == 12345.f))
+      store_levels4(a.qx, q_dst + c * 64, q[0], q[1], q[2], q[3], A8);
+    slot = slot == 2 ? 0 : slot + 1;
+    if (SPQ_XP_DIAG & 128) {
+      asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]) : "memory");   // the MFMAs are done
+      SPQ_XP_STAMP(t3);
+      st_wait += t2a - t2; st_bar += t2 - t1; st_body += t3 - t2a;   // [0]: the copies' issue, [1]: barrier, [2]: the rest of the body
     }
   }
+#if SPQ_XP_DIAG & 128
+  if (lane == 0 && blockIdx.x < 2048) {
+    unsigned long long* o = g_xp_stamps + ((int64_t)blockIdx.x * 8 + w) * 4;
+    o[0] = st_wait; o[1] = st_bar; o[2] = st_body; o[3] = __builtin_readcyclecounter() - t_begin;
+  }
+#endif
+  __syncthreads();                                          // the ring is free for the reduction
+  if ((SPQ_XP_DIAG & 16) && a.M != 12345) return;
+  xpass16_finish<ROWS>(a, acc, reinterpret_cast<float*>(xsm), m0, tid);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -2343,6 +2519,12 @@ struct AttrOnce {
 
 int prepare_fill(const spq_prepare_args* q, PrepArgs& a, int& at_blocks, bool& wave_ok);
 
+#if SPQ_XP_DIAG & 128
+extern "C" int spq_debug_xp_stamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_xp_stamps), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   const bool x3 = a->path == SPQ_PATH_F16X3;
   const int i8nl = i8_limbs_of(a->path);
@@ -2455,7 +2637,28 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)xpass_rows16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, XP16R_LDS);
       (void)hipFuncSetAttribute((const void*)xpass_rows16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, XP16R_LDS);
     }
-    if (x.ascale && a->r > 0) xpass_panel16_kernel<<<xgrid, 512, XP16_LDS, st>>>(x);
+    const char* xs_env = getenv("SPQ_XPASS_STREAM");        // 0: the panel kernels, 1 / unset: auto, 16 / 32: forced row count (tuning, tests)
+    const int stream16 = xs_env ? atoi(xs_env) : 1;
+    const bool use_stream = stream16 && a->r > 0 && !x.limbs && !x.lora_fq && !x.ascale && prep_rows == 0;
+    if (use_stream) {
+      if (AttrOnce once(7); once.first) {
+#define SPQ_XS_ATTR(R, A8, LN) (void)hipFuncSetAttribute((const void*)xpass_stream_kernel<R, A8, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, xs_lds(R))
+        SPQ_XS_ATTR(16, 0, false); SPQ_XS_ATTR(16, 1, false); SPQ_XS_ATTR(16, 2, false);
+        SPQ_XS_ATTR(16, 0, true); SPQ_XS_ATTR(16, 1, true); SPQ_XS_ATTR(16, 2, true);
+        SPQ_XS_ATTR(32, 0, false); SPQ_XS_ATTR(32, 1, false); SPQ_XS_ATTR(32, 2, false);
+        SPQ_XS_ATTR(32, 0, true); SPQ_XS_ATTR(32, 1, true); SPQ_XS_ATTR(32, 2, true);
+#undef SPQ_XS_ATTR
+      }
+      // 32-row workgroups halve the FQ(A)^T traffic through L2; taken once they still cover every CU
+      const bool r32 = stream16 == 32 || (stream16 != 16 && (a->M + 31) / 32 >= gemm_grid(1 << 30));
+      const bool ln = x.ln_w != nullptr;
+#define SPQ_XS_LAUNCH(R, A8, LN) xpass_stream_kernel<R, A8, LN><<<(unsigned)((a->M + R - 1) / R), R * 16, xs_lds(R), st>>>(x)
+#define SPQ_XS_PICK(R) do { if (ln) { if (x.a8 == 0) SPQ_XS_LAUNCH(R, 0, true); else if (x.a8 == 1) SPQ_XS_LAUNCH(R, 1, true); else SPQ_XS_LAUNCH(R, 2, true); } \
+                            else { if (x.a8 == 0) SPQ_XS_LAUNCH(R, 0, false); else if (x.a8 == 1) SPQ_XS_LAUNCH(R, 1, false); else SPQ_XS_LAUNCH(R, 2, false); } } while (0)
+      if (r32) SPQ_XS_PICK(32); else SPQ_XS_PICK(16);
+#undef SPQ_XS_PICK
+#undef SPQ_XS_LAUNCH
+    } else if (x.ascale && a->r > 0) xpass_panel16_kernel<<<xgrid, 512, XP16_LDS, st>>>(x);
     else if (use_rows16 && prep_rows > 0) {
       const unsigned xg16 = (unsigned)((a->M + XR16 - 1) / XR16);
       if (pa.nl == 1) xpass_rows16_kernel<2><<<xg16, 256, XP16R_LDS, st>>>(x, pa, prep_rows);
