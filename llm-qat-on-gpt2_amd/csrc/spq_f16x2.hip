@@ -1868,6 +1868,32 @@ constexpr int T128_STAGE = T128_STAGE_A + 2 * STAGE_B;     // 48 KB
 #ifndef T128_DIAG      // tools/gemm_bench only (the library builds 0): 1 = no copies after a tile's first stage, 2 = no MFMAs /
 #define T128_DIAG 0    // fragment reads, 4 = no epilogue stores
 #endif
+#ifndef T128_ORDER
+#define T128_ORDER 0
+#endif
+// Issue priority of the CU's three resident workgroups.  Left alone (0) the SIMD arbiter favours the oldest wave: stamped at the
+// headline shape, the first-dispatched third of the grid finishes its two tiles after 56 us, the second after 60 us and the
+// last-dispatched after 75 us, alone on its CU for the last 15 us -- the kernel lasts as long as the starved third.  7: every
+// workgroup takes the priorities 0/1/2 in turn, a sixth of its stages each, offset by its dispatch third, so the three advance
+// together (ends 64-73 us, kernel 80.5 -> 77.2 us).  1-6: other schedules tried in tools/t128_bench.hip (fixed priorities only move
+// the starvation to another third; rotation every stage 77.1-77.5; mirrored per tile 77.4-78.1).
+#ifndef T128_PRIO
+#define T128_PRIO 7
+#endif
+#ifndef T128_PRIO_DIV
+#define T128_PRIO_DIV 6
+#endif
+#ifndef T128_PRIO_MID
+#define T128_PRIO_MID 1
+#endif
+#ifndef T128_PRIO_HI
+#define T128_PRIO_HI 2
+#endif
+#if T128_DIAG & 8      // in-kernel stamps of the stage's segments, summed per wave into GemmF16Args::dbg[(block * 4 + wave) * 8 ..]
+#define T128_STAMP(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define T128_STAMP(v) const unsigned long long v = 0
+#endif
 constexpr bool T128_DEFER = T128_WGS == 3;
 constexpr int T128_LDS = T128_DEFER ? T128_STAGE : T128_STAGE + 4 * EPI_WAVE;
 #ifndef T128_GROUP_M
@@ -1956,19 +1982,70 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
       }
   };
   // stage: its copies were issued earlier.  Afterwards the buffer is free and the next stage (nt of tile nbm, nbn) goes in.
+  unsigned long long st_sum[4] = {0, 0, 0, 0};
+  int prio_ctr = (int)(blockIdx.x / (gridDim.x / 3 > 0 ? gridDim.x / 3 : 1));
+  int stage_ctr = 0;
   auto stage = [&](bool two, bool have_next, int nt, int nbm, int nbn) {
+#if T128_PRIO == 4     // rotate the issue priority of the CU's three workgroups stage by stage
+    prio_ctr = prio_ctr == 2 ? 0 : prio_ctr + 1;
+    if (prio_ctr == 0) __builtin_amdgcn_s_setprio(0); else if (prio_ctr == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+#endif
+#if T128_PRIO == 6 || T128_PRIO == 7   // the three workgroups of a CU take the three priorities in turn, 1/T128_PRIO_DIV of their stages each
+    {
+      constexpr int DIV = T128_PRIO == 6 ? 3 : T128_PRIO_DIV;
+      const int per = max(1, (T * ((nwg + gstride - 1) / gstride) + DIV - 1) / DIV);
+      if (stage_ctr % per == 0) {
+        const int pr = (prio_ctr + stage_ctr / per) % 3;
+        if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(T128_PRIO_MID); else __builtin_amdgcn_s_setprio(T128_PRIO_HI);
+      }
+      ++stage_ctr;
+    }
+#endif
+    T128_STAMP(s0);
     __syncthreads();                                         // vmcnt(0) + barrier: the stage has landed
     Frags f0, f1;
+#if T128_ORDER == 1   // tools/t128_bench only
+    // fragments into registers, barrier, the NEXT stage's copies, and only then this stage's MFMAs: the copies travel under
+    // the workgroup's own 64 MFMAs per wave instead of after them.  Measured: 85.5 -> 81 us with two workgroups per CU (no gain
+    // over three workgroups in the order below, 80 us); with three it needs both fragment sets live across the copies' address
+    // arithmetic and spills (168 VGPRs + 144 B of scratch: 113 us)
+    if (!(T128_DIAG & 2)) { load_frags(f0, 0, two); load_frags(f1, 1, two); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+    if (have_next) issue(nt, nbm, nbn);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(T128_DIAG & 2)) { mfma_block(f0, two); mfma_block(f1, two); }
+#else
+    T128_STAMP(s1);                                          // [0] s0 -> s1: waiting for the stage's copies + barrier
     if (!(T128_DIAG & 2)) {
       load_frags(f0, 0, two);
       load_frags(f1, 1, two); mfma_block(f0, two);
       mfma_block(f1, two);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // my fragment reads are complete (and may not sink below)
+    if (T128_DIAG & 8) asm volatile("s_nop 0" :: "v"(acc[3][3][0]), "v"(acc[0][0][0]) : "memory");   // ... and the MFMAs (stamps only)
+    T128_STAMP(s2);                                          // [1] s1 -> s2: fragment reads + MFMAs
     __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave has read its fragments
+    T128_STAMP(s3);                                          // [2] s2 -> s3: barrier
     if (have_next) issue(nt, nbm, nbn);
+    T128_STAMP(s4);                                          // [3] s3 -> s4: issuing the next stage's copies
+    if (T128_DIAG & 8) { st_sum[0] += s1 - s0; st_sum[1] += s2 - s1; st_sum[2] += s3 - s2; st_sum[3] += s4 - s3; }
+#endif
   };
 
+#if T128_PRIO == 1
+  if (blockIdx.x >= 2 * (gridDim.x / 3)) __builtin_amdgcn_s_setprio(1);
+#elif T128_PRIO == 2
+  if (blockIdx.x >= 2 * (gridDim.x / 3)) __builtin_amdgcn_s_setprio(2); else if (blockIdx.x >= gridDim.x / 3) __builtin_amdgcn_s_setprio(1);
+#elif T128_PRIO == 5
+  if (blockIdx.x >= 2 * (gridDim.x / 3)) __builtin_amdgcn_s_setprio(2); else if (blockIdx.x >= gridDim.x / 3) __builtin_amdgcn_s_setprio(1);
+#elif T128_PRIO == 3
+  if (blockIdx.x >= 2 * (gridDim.x / 3)) __builtin_amdgcn_s_setprio(3); else if (blockIdx.x >= gridDim.x / 3) __builtin_amdgcn_s_setprio(1);
+#endif
+  T128_STAMP(t_kernel);
+#if T128_DIAG & 8
+  const unsigned long long t_real = __builtin_amdgcn_s_memrealtime();
+#endif
   issue(0, bm, bn);
   while (true) {
 #pragma unroll
@@ -2055,6 +2132,10 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
       }
     }
     if (!more) break;
+#if T128_PRIO == 5     // second tile: the priorities of the first, mirrored
+    { const int slot = (int)(blockIdx.x / (gridDim.x / 3 > 0 ? gridDim.x / 3 : 1));
+      if (slot == 0) __builtin_amdgcn_s_setprio(2); else if (slot == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
     if (T128_DEFER) {                                       // the slices are done with: the next tile's first stage may land on them
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
@@ -2062,6 +2143,16 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
     }
     p = pn; bm = nbm; bn = nbn;
   }
+#if T128_DIAG & 8
+  if (g.dbg && lane == 0) {
+    unsigned long long* o = g.dbg + ((int64_t)blockIdx.x * 4 + w) * 8;
+    for (int i = 0; i < 4; ++i) o[i] = st_sum[i];
+    o[4] = __builtin_readcyclecounter() - t_kernel;
+    const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+    o[5] = t_end - t_real;                                  // constant 100 MHz counter: o[4] / o[5] = shader clock / 100 MHz
+    o[6] = t_real; o[7] = t_end;
+  }
+#endif
 }
 
 constexpr int U8_SLOT_A = GM * 64;                         // 16 KB (BASE: 256 x 64 B;  LORA: 256 x 32 fp16)
