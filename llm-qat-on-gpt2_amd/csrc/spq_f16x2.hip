@@ -2124,7 +2124,7 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
             o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
             if (EPI == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
             float* dst = g.y + (int64_t)m * g.N + n;
-            if (T128_DIAG & 4) { if (o.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }
+            if (T128_DIAG & 4) { if (o.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }   // (non-temporal stores: no change, 79.3 vs 79.2 us)
             else if (interior) *reinterpret_cast<float4*>(dst) = o;
             else if (n_ok && m < g.M) *reinterpret_cast<float4*>(dst) = o;
           }
@@ -2853,9 +2853,10 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     t128 = !e ? 2 : (e[0] == '1' ? 1 : 0);     // unset: by shape (below), 1: always, 0: never
   }
   if ((a->N & 3) != 0 && !mfma16) { set_error("spq_linear_lora_fwd: N %% 4 != 0 needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
-  // measured (tools/config_bench.py): two decoupled 128x128 workgroups per CU win 1.5-3 % while M <= 8192 and lose 3-6 % at
-  // M = 32768 and on the three-product path (1.5x the copy traffic)
-  const bool use_t128 = t128 == 1 || (t128 == 2 && !x3 && a->M <= 12288);
+  // measured (tools/config_bench.py), round 2 with three workgroups per CU taking the issue priorities in turn: the 128x128
+  // kernel wins at every shape of SURVEY 8(d) -- config 3 (M = 32768) 1.466 -> 1.356 ms over the four linears, config 5 (the
+  // three-product path) 27.8 -> 27.4 ms -- so the 256x128 kernel is what SPQ_GEMM_T128=0 selects
+  const bool use_t128 = t128 != 0;
   if (use_t128 && mfma16 && (a->N & 3) == 0) {
     const int ntiles = 2 * g.tiles_m * g.tiles_n;
     const unsigned cus2 = T128_WGS * gemm_grid(1 << 30);

@@ -28,7 +28,8 @@ def test_random_cpt_layers_against_oracle():
 
 
 
-@pytest.mark.parametrize("switch", ["SPQ_MFMA16=0", "SPQ_GEMM_T128=1", "SPQ_GEMM_T128=0", "SPQ_LORA_DOWN_F16=1", "SPQ_OVERLAP_PREPARE=1", "SPQ_XPASS_ROWS16=0"])
+@pytest.mark.parametrize("switch", ["SPQ_MFMA16=0", "SPQ_GEMM_T128=1", "SPQ_GEMM_T128=0", "SPQ_LORA_DOWN_F16=1", "SPQ_OVERLAP_PREPARE=1", "SPQ_XPASS_ROWS16=0",
+                                    "SPQ_XPASS_STREAM=0", "SPQ_XPASS_STREAM=16", "SPQ_XPASS_STREAM=32"])
 def test_alternative_kernels_stay_parity_green(switch):
     """The opt-in kernels of DESIGN.md 'Run-time switches' (read once per process, hence a child process each): a short forward
     sweep (and, for the LoRA-down variant, a backward sweep, which uses it for g . FQ(B)^T) under each switch."""
