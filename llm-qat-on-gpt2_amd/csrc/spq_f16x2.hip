@@ -337,8 +337,17 @@ __device__ __forceinline__ void prep_row_wave_i8(const PrepArgs& a, int n, int l
 // LoRA-B column B[0..r-1][n] staged contiguously by the caller (LDS) instead of the strided global read.
 // MODE 0: two fp16 limbs of W' * 2^e[n] (F16X2 / F16X3).  MODE 1: the weight's own integer levels as int8 (SPQ_PATH_I8).
 template <int MODE, int MAXI = PREP_MAXI>    // MAXI: float4 loads per lane that cover a row (K <= 256 * MAXI)
-__device__ __forceinline__ void prep_row_wave(const PrepArgs& a, int n, int lane, const float* sb_row) {
-  if constexpr (MODE != 0) { prep_row_wave_i8<MAXI>(a, n, lane, sb_row); return; }
+__device__ __forceinline__ void prep_row_wave(const PrepArgs& a, int n, int lane, const float* sb_row, float* stage_dst0 = nullptr,
+                                              float* stage_dst1 = nullptr, float stage_v0 = 0.f, float stage_v1 = 0.f) {
+  // stage_dst*: the workgroup's LoRA-B columns were fetched into registers BEFORE this row's loads were issued (one memory round
+  // trip for both); they go to LDS -- and the workgroup meets -- only where the row first needs them.  Every wave of the
+  // workgroup must then come through here (no padding rows in a staged workgroup).
+  auto stage_b = [&]() {
+    if (stage_dst0) *stage_dst0 = stage_v0;
+    if (stage_dst1) *stage_dst1 = stage_v1;
+    __syncthreads();
+  };
+  if constexpr (MODE != 0) { if (stage_dst0 || stage_dst1) stage_b(); prep_row_wave_i8<MAXI>(a, n, lane, sb_row); return; }
   _Float16* whi = a.Whi + (int64_t)n * a.Kp;
   _Float16* wlo = a.Wlo + (int64_t)n * a.Kp;
   _Float16* bhi = a.Bhi ? a.Bhi + (int64_t)n * a.Rp : nullptr;
@@ -355,29 +364,47 @@ __device__ __forceinline__ void prep_row_wave(const PrepArgs& a, int n, int lane
   }
   const float swn = a.sw[a.w_pc ? n : 0], zwn = a.zw[a.w_pc ? n : 0];
   const float4* Wrow = reinterpret_cast<const float4*>(a.W + (int64_t)n * a.K);
-  float4 wq[MAXI];
-  float vmax = 0.f;
+  // every load of the row first (W and the input scales), then the arithmetic: written as one loop the compiler waited for each
+  // 16-byte piece and then for its scales before asking for the next -- six dependent memory round trips per 768-element row --
+  // and the quantizer dispatch (min-max / log, the fp64 log2 of the latter) sat inside it, 33 000 instructions of ISA
+  float4 wq[MAXI], sc[MAXI];
+  // (branch-free inside the loops: a guarded load made the compiler wait for it at the join)
+  if (a.x_pc) {
 #pragma unroll
-  for (int i = 0; i < MAXI; ++i) {
-    const int k4 = lane + 64 * i;
-    if (k4 < k4n) {
-      const float4 v = Wrow[k4];
-      float4 q;
-      q.x = fq_dispatch(v.x, swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
-      q.y = fq_dispatch(v.y, swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
-      q.z = fq_dispatch(v.z, swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
-      q.w = fq_dispatch(v.w, swn, zwn, a.w_bits, a.w_qtype, a.w_sym);
-      float4 sc;
-      if (a.x_pc) sc = *reinterpret_cast<const float4*>(a.sx + 4 * k4);
-      else { const float s1 = a.sx[0]; sc = make_float4(s1, s1, s1, s1); }
-      q.x *= sc.x; q.y *= sc.y; q.z *= sc.z; q.w *= sc.w;    // W' = fl32(FQ(W) * sx)
-      wq[i] = q;
-      vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w))));
+    for (int i = 0; i < MAXI; ++i) {
+      const int kc = min(lane + 64 * i, k4n - 1);
+      wq[i] = Wrow[kc];
+      sc[i] = *reinterpret_cast<const float4*>(a.sx + 4 * kc);
+    }
+  } else {
+    const float s1 = a.sx[0];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      wq[i] = Wrow[min(lane + 64 * i, k4n - 1)];
+      sc[i] = make_float4(s1, s1, s1, s1);
     }
   }
+  float vmax = 0.f;
+  auto fold = [&](auto fq) {                                // W' = fl32(FQ(W) * sx), row maximum
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int k4 = lane + 64 * i;
+      if (k4 < k4n) {
+        float4 q;
+        q.x = fq(wq[i].x) * sc[i].x; q.y = fq(wq[i].y) * sc[i].y; q.z = fq(wq[i].z) * sc[i].z; q.w = fq(wq[i].w) * sc[i].w;
+        wq[i] = q;
+        vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w))));
+      }
+    }
+  };
+  if (a.w_bits >= 32) fold([](float v) { return v; });
+  else if (a.w_qtype == SPQ_MINMAX && a.w_sym) fold([&](float v) { return fq_value<SPQ_MINMAX, true>(v, swn, zwn, a.w_bits); });
+  else if (a.w_qtype == SPQ_MINMAX) fold([&](float v) { return fq_value<SPQ_MINMAX, false>(v, swn, zwn, a.w_bits); });
+  else fold([&](float v) { return fq_dispatch(v, swn, zwn, a.w_bits, a.w_qtype, a.w_sym); });
   float bq[2] = {0.f, 0.f};
   if (a.B) {
     const float sbn = a.sb[a.b_pc ? n : 0], zbn = a.zb[a.b_pc ? n : 0];
+    if (stage_dst0 || stage_dst1) stage_b();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int j = lane + 64 * i;
@@ -420,7 +447,7 @@ __device__ __forceinline__ void prep_row_wave(const PrepArgs& a, int n, int lane
   }
 }
 
-template <int MODE>
+template <int MODE, int MAXI = PREP_MAXI>   // MAXI = 4: rows of at most 1024 elements
 __global__ __launch_bounds__(256) void prep_wave_kernel(PrepArgs a, int at_blocks) {
   // the FQ(A)^T tiles come FIRST in the grid (they are the longer workgroups: a tail of them cost ~2 us)
   if ((int)blockIdx.x < at_blocks) { fq_transpose_tile(a, blockIdx.x); return; }
@@ -428,13 +455,17 @@ __global__ __launch_bounds__(256) void prep_wave_kernel(PrepArgs a, int at_block
   // the four rows' LoRA-B columns B[j][n0 .. n0+3] are 16-byte runs: one coalesced-per-j load by the workgroup, staged in LDS,
   // instead of a strided scalar read per (row, j) from every wave
   __shared__ float sB[4][128];
-  const bool staged = a.B && n0 + 3 < a.N && (a.N & 3) == 0;
+  const bool staged = a.B && n0 + 3 < a.N && (a.N & 3) == 0;      // (then r <= 128: at most two elements per thread)
+  float* d0 = nullptr; float* d1 = nullptr;
+  float v0 = 0.f, v1 = 0.f;
   if (staged) {
-    for (int e = threadIdx.x; e < a.r * 4; e += 256) sB[e & 3][e >> 2] = a.B[(int64_t)(e >> 2) * a.N + n0 + (e & 3)];
-    __syncthreads();
+    const int e0 = threadIdx.x, e1 = threadIdx.x + 256;
+    d0 = &sB[e0 & 3][e0 >> 2];                             // every thread takes part in the barrier, with or without an element
+    if (e0 < a.r * 4) v0 = a.B[(int64_t)(e0 >> 2) * a.N + n0 + (e0 & 3)];
+    if (e1 < a.r * 4) { d1 = &sB[e1 & 3][e1 >> 2]; v1 = a.B[(int64_t)(e1 >> 2) * a.N + n0 + (e1 & 3)]; }
   }
   const int wv = threadIdx.x >> 6;
-  prep_row_wave<MODE>(a, n0 + wv, threadIdx.x & 63, staged ? &sB[wv][0] : nullptr);
+  prep_row_wave<MODE, MAXI>(a, n0 + wv, threadIdx.x & 63, staged ? &sB[wv][0] : nullptr, d0, d1, v0, v1);
 }
 
 // FQ(A)^T alone (the first of the two operand launches when the row work rides in the activation pass)
@@ -2952,7 +2983,10 @@ extern "C" int spq_prepare_f16x2_args(const spq_prepare_args* q, spq_stream_t st
   const int rc = prepare_fill(q, a, at_blocks, wave_ok);
   if (rc) return rc;
   const unsigned grid = (unsigned)(a.row_blocks + at_blocks);
-  if (a.nl == 1) prep_wave_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a, at_blocks);
+  const bool short_rows = q->K <= 4 * 64 * 4;
+  if (a.nl == 1 && short_rows) prep_wave_kernel<1, 4><<<grid, 256, 0, (hipStream_t)stream>>>(a, at_blocks);
+  else if (a.nl == 1) prep_wave_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a, at_blocks);
+  else if (wave_ok && short_rows) prep_wave_kernel<0, 4><<<grid, 256, 0, (hipStream_t)stream>>>(a, at_blocks);
   else if (wave_ok) prep_wave_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a, at_blocks);
   else prep_f16x2_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   return check_launch("spq_prepare_f16x2");
