@@ -164,15 +164,22 @@ __device__ __forceinline__ float wave_max_nan(float v) {
 // x.var(unbiased=False) defines it, over a row held in registers (NV float4 per lane, element c = (64 i + lane) * 4).
 // Shared by layernorm_kernel and by the activation pass that applies the LayerNorm on the fly, so both produce the same bits.
 // Extra iterations (c >= cols) add nothing: any NV that covers the row gives the same result.
+// ln_row_load: the row's pieces into registers, every load issued before anything consumes one (branch-free: a guarded load
+// made the compiler wait for each piece at the join, i.e. NV dependent memory round trips per row).  ln_row_reduce: the
+// statistics of a loaded row.  ln_row_stats = both.
 template <int NV>
-__device__ __forceinline__ void ln_row_stats(const float* __restrict__ xr, int cols, float eps, int lane, float4 (&v)[NV],
-                                             float& mean, float& den) {
+__device__ __forceinline__ void ln_row_load(const float* __restrict__ xr, int cols, int lane, float4 (&v)[NV]) {
+  const int last = (cols >> 2) - 1;                         // cols % 4 == 0
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + 4 * min(i * 64 + lane, last));
+}
+template <int NV>
+__device__ __forceinline__ void ln_row_reduce(const float4 (&v)[NV], int cols, float eps, int lane, float& mean, float& den) {
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
-    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < cols) { v[i] = *reinterpret_cast<const float4*>(xr + c); sum += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    if (c < cols) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
@@ -189,6 +196,12 @@ __device__ __forceinline__ void ln_row_stats(const float* __restrict__ xr, int c
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
   den = sqrtf(sq / (float)cols + eps);           // torch.sqrt(var + eps)
+}
+template <int NV>
+__device__ __forceinline__ void ln_row_stats(const float* __restrict__ xr, int cols, float eps, int lane, float4 (&v)[NV],
+                                             float& mean, float& den) {
+  ln_row_load<NV>(xr, cols, lane, v);
+  ln_row_reduce<NV>(v, cols, eps, lane, mean, den);
 }
 // one normalised element: weight * ((x - mean) / den) + bias, each operation its own rounding (-ffp-contract=off)
 __device__ __forceinline__ float ln_apply(float x, float mean, float den, float w, float b) { return w * ((x - mean) / den) + b; }

@@ -243,14 +243,15 @@ struct XPassArgs {
 // its own 16-byte slot of each landed chunk in place (the slot the level pass reads), before anything else reads the panel.
 __device__ __forceinline__ void ln_panel_stats(const XPassArgs& a, int m0, int rows, float* st) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float4 v[4][4];                                           // the wave's four rows: all 16 loads in flight together
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ln_row_load<4>(a.x + (int64_t)min(m0 + min(4 * w + i, rows - 1), a.M - 1) * a.K, a.K, lane, v[i]);
+#pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 4 * w + i;
-    if (row < rows) {
-      float4 v[4];
-      float mean, den;
-      ln_row_stats<4>(a.x + (int64_t)min(m0 + row, a.M - 1) * a.K, a.K, a.ln_eps, lane, v, mean, den);
-      if (lane == 0) { st[2 * row] = mean; st[2 * row + 1] = den; }
-    }
+    float mean, den;
+    ln_row_reduce<4>(v[i], a.K, a.ln_eps, lane, mean, den);
+    if (row < rows && lane == 0) { st[2 * row] = mean; st[2 * row + 1] = den; }
   }
 }
 __device__ __forceinline__ void ln_panel_apply(const XPassArgs& a, char* xs, int chunk_stride, int nch, int p0, int q_row, int q_pos,
@@ -1788,11 +1789,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16
       stage((base + t + 1) & 1, false, !last || more, last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
     }
     if (nl > 0) {                                        // LoRA partial sums -> units of the base sum: * 2^-g[m]
+      f32x4 riv[4];                                        // the four loads first: one memory round trip, not four
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) riv[tm] = *reinterpret_cast<const f32x4*>(g.rowinv + bm + wm * 64 + tm * 16 + 4 * q4);
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                      // C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + e
-          float ri = g.rowinv[bm + wm * 64 + tm * 16 + 4 * q4 + e];
+          float ri = riv[tm][e];
           if (AL == 2) ri *= lora_to_base;
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn) acc[tm][tn][e] *= ri;
@@ -2094,12 +2098,15 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
       const bool last = (t + 2 == T);
       stage(false, !last || (more && !T128_DEFER), last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
     }
-    if (nl > 0) {
+    if (nl > 0) {                                        // LoRA partial sums -> units of the base sum: * 2^-g[m]
+      f32x4 riv[4];                                        // the four loads first: one memory round trip, not four
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) riv[tm] = *reinterpret_cast<const f32x4*>(g.rowinv + bm + wm * 64 + tm * 16 + 4 * q4);
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float ri = g.rowinv[bm + wm * 64 + tm * 16 + 4 * q4 + e];
+          float ri = riv[tm][e];
           if (AL == 2) ri *= lora_to_base;
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn) acc[tm][tn][e] *= ri;

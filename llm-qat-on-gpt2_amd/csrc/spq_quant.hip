@@ -212,11 +212,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   float4 v[NV];
   float mean, den;
   ln_row_stats<NV>(xr, cols, eps, lane, v, mean, den);
+  float4 wvs[NV], bvs[NV];                                   // weight / bias pieces: all loads before the arithmetic (see ln_row_load)
+  const int last = (cols >> 2) - 1;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = 4 * min(i * 64 + lane, last);
+    wvs[i] = *reinterpret_cast<const float4*>(w + c4); bvs[i] = *reinterpret_cast<const float4*>(b + c4);
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < cols) {
-      const float4 wv = *reinterpret_cast<const float4*>(w + c), bv = *reinterpret_cast<const float4*>(b + c);
+      const float4 wv = wvs[i], bv = bvs[i];
       float4 o;
       o.x = ln_apply(v[i].x, mean, den, wv.x, bv.x); o.y = ln_apply(v[i].y, mean, den, wv.y, bv.y);
       o.z = ln_apply(v[i].z, mean, den, wv.z, bv.z); o.w = ln_apply(v[i].w, mean, den, wv.w, bv.w);
