@@ -25,6 +25,13 @@ def make_pair(pkg, M, K, N, r, bits, qtype, per_channel, seed, batch=4, alpha=No
     """(product layer on GPU, calibrated oracle layer, activations)"""
     from oracle import ref_cpu as O
     W, bias, A, B, x0, x1 = O.make_workload(M, K, N, r, seed=seed, batch=batch)
+    return make_pair_from(pkg, W, bias, A, B, x0, x1, bits, qtype, per_channel, alpha=alpha, symmetric=symmetric)
+
+
+def make_pair_from(pkg, W, bias, A, B, x0, x1, bits, qtype, per_channel, alpha=None, symmetric=True):
+    from oracle import ref_cpu as O
+    N, K = W.shape
+    r = A.shape[1]
     alpha = r if alpha is None else alpha
     ol = O.build_calibrated_layer(W, bias, A, B, [x0, x1], bits, qtype, per_channel, alpha, r, symmetric=symmetric)
     layer = pkg.SPLinearWithLoRA(K, N, [bits, 32], {bits: r, 32: 0}, {bits: alpha, 32: 0}, {bits: qtype, 32: None},
@@ -52,6 +59,8 @@ SHAPES = [
     ("mlp_cproj_4bit",     2048, 3072, 768,  64, 4, "minmax", True),      # K = 3072: four activation panels
     ("medium_cfc_log6",    1024, 1024, 4096, 64, 6, "log",    True),      # configs[4]: GPT-2-medium dims, log 6-bit
     ("medium_cproj_log6",  1024, 4096, 1024, 64, 6, "log",    True),
+    ("medium_cattn_log6",  1024, 1024, 3072, 64, 6, "log",    True),      # the other two linears of a GPT-2-medium block
+    ("medium_aproj_log6",  1024, 1024, 1024, 64, 6, "log",    True),
     ("ragged_rank16",      1000, 320,  200,  16, 4, "minmax", True),      # edge tiles in M and N, rank < 64
     ("tiny",               3,    64,   8,    8,  3, "minmax", False),
     ("rank128",            512,  256,  384,  128, 4, "minmax", True),     # two 64-wide LoRA blocks
@@ -94,6 +103,31 @@ def test_linear_shapes_against_oracle(pkg, name, M, K, N, r, bits, qtype, pc):
         with torch.no_grad():
             assert_close_y(layer(x1.to(DEV)), ol.forward(x1), f"{name}.y_f32", tol)
         assert layer._last_path == pkg._lib.PATH_F32
+
+
+@pytest.mark.parametrize("bits,K", [(4, 4096), (8, 4096), (12, 2048)])
+def test_coherent_limb_error_large_k(pkg, bits, K):
+    """The two-limb fp16 weight operand carries 22 significant bits (truncation <= 2^-22 |W'| per element).  Worst case for that
+    error: every product of a row has the SAME sign (no cancellation in the sum, so the truncation errors cannot average out
+    against a small result) and K is large.  All-positive activations, weights and LoRA factors at K = 2048 / 4096; per-channel
+    scales so that the folded weight W' = FQ(W) * sx[k] really has 24-bit mantissas."""
+    M, N, r = 512, 256, 64
+    g = torch.Generator().manual_seed(1234 + bits)
+    W = (torch.randn(N, K, generator=g) * 0.02).abs() + 1e-4
+    bias = torch.randn(N, generator=g).abs() * 0.02
+    A = torch.rand(K, r, generator=g) * (1.0 / K ** 0.5)
+    B = torch.rand(r, N, generator=g) * 0.01
+    x0 = torch.randn(4, M // 4, K, generator=g).abs() * (1.0 + torch.rand(K, generator=g) * 3.0)
+    x1 = torch.randn(4, M // 4, K, generator=g).abs() * (1.0 + torch.rand(K, generator=g) * 3.0)
+    layer, ol, x0, x1 = make_pair_from(pkg, W, bias, A, B, x0, x1, bits, "minmax", True)
+    with torch.no_grad():
+        y = layer(x1.to(DEV))
+    assert layer._last_path == pkg._lib.PATH_F16X2
+    ref = ol.forward(x1)
+    assert (ref > 0).all()
+    assert_close_y(y, ref, f"coherent_{bits}bit_K{K}", 1e-5)
+    rel = ((y.cpu() - ref).abs() / ref.abs()).max().item()        # no rms term needed: nothing cancels
+    assert rel < 1e-5, rel
 
 
 @pytest.mark.parametrize("qtype,bits,pc", [("minmax", 4, True), ("minmax", 8, False), ("log", 5, True)])

@@ -29,6 +29,9 @@ constexpr int T256_LDS = T256_STAGE;
 #ifndef T256_PRIO_PERIOD   // the CU's two workgroups swap issue priority every T256_PRIO_PERIOD stages (0: leave the arbiter alone)
 #define T256_PRIO_PERIOD 7
 #endif
+#ifndef T256_RING
+#define T256_RING 1
+#endif
 #ifndef T256_GROUP_M    // whole-tile rows (256 rows each) per L2 band of the tile order
 #define T256_GROUP_M 4
 #endif
@@ -39,6 +42,63 @@ struct T256Plan {
   int full_bands;
   int grid;
 };
+
+template <int TM, int AL, int EPI>
+__device__ __forceinline__ void t256_epilogue(const GemmF16Args& g, char* smem, f32x4 (&acc)[TM][4], const int bm, const int bn, const int w,
+                                              const int lane, const float out_scale) {
+  constexpr int WROWS = TM * 16;
+  const int wm = w >> 1, wn = w & 1;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  // epilogue: per-wave transpose slices inside the (now free) stage buffer, whole 128-B lines per store
+  float4 ep_rs[2], ep_bv[2];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
+    ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
+    if (n < g.N) {
+      ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);
+      if (AL == 2) { ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale; }
+      if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
+    }
+  }
+  {
+    char* eb = smem + w * (T256_STAGE / 4);                  // 16 KB per wave: four 16 x 32 blocks per round
+    const int c4 = (lane & 7) * 4;
+    const bool interior = (bm + 32 * TM <= g.M) && (bn + GN <= g.N);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = bn + wn * 64 + tn * 32 + c4;
+      const bool n_ok = n < g.N;
+      const float4 rs = ep_rs[tn], bv = ep_bv[tn];
+#pragma unroll
+      for (int t4 = 0; t4 < TM; t4 += 4) {
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            *reinterpret_cast<float*>(eb + tq * EPI_WAVE + (4 * q4 + e) * 144 + l15 * 4) = acc[t4 + tq][2 * tn][e];
+            *reinterpret_cast<float*>(eb + tq * EPI_WAVE + (4 * q4 + e) * 144 + (16 + l15) * 4) = acc[t4 + tq][2 * tn + 1][e];
+          }
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(eb + (j >> 1) * EPI_WAVE + ((j & 1) * 8 + (lane >> 3)) * 144 + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int m = bm + wm * WROWS + (t4 + (j >> 1)) * 16 + (j & 1) * 8 + (lane >> 3);
+          float4 o;
+          o.x = v[j].x * rs.x + bv.x; o.y = v[j].y * rs.y + bv.y; o.z = v[j].z * rs.z + bv.z; o.w = v[j].w * rs.w + bv.w;
+          if (EPI == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
+          float* dst = g.y + (int64_t)m * g.N + n;
+          if (T256_DIAG & 4) { if (o.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }
+          else if (interior) *reinterpret_cast<float4*>(dst) = o;
+          else if (n_ok && m < g.M) *reinterpret_cast<float4*>(dst) = o;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the slices are done with: the next tile's copies may land on them
+  __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+}
 
 // one tile: rows [bm, bm + 32 * TM) x columns [bn, bn + 128); self-contained (first copies ... epilogue, trailing barrier)
 template <int TM, int AL, int EPI>
@@ -180,55 +240,149 @@ __device__ __forceinline__ void t256_tile(const GemmF16Args& g, char* smem, cons
 #if T256_DIAG & 8
   const unsigned long long e0 = __builtin_readcyclecounter();
 #endif
-  // epilogue: per-wave transpose slices inside the (now free) stage buffer, whole 128-B lines per store
-  float4 ep_rs[2], ep_bv[2];
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
-    ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
-    if (n < g.N) {
-      ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);
-      if (AL == 2) { ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale; }
-      if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
+  t256_epilogue<TM, AL, EPI>(g, smem, acc, bm, bn, w, lane, out_scale);
+#if T256_DIAG & 8
+  st_sum[4] += __builtin_readcyclecounter() - e0;
+#endif
+}
+
+
+// ---- ring variant (T256_RING): the 64-KB buffer is TWO 32-deep half stages ([A 256 x 64 B][B-hi 128 x 64 B][B-lo]: 32 KB each).
+// Per half stage: wait for its copies + barrier (which also says that every wave has read the other slot), issue the NEXT half
+// stage's copies into the other slot, then this one's fragment reads and MFMAs -- the workgroup's own matrix phase covers its own
+// copy latency; one barrier per half stage.  Rows are 64 B = four 16-B chunks; chunk c of row r sits at position
+// c ^ g[(r >> 2) & 3], g = {0, 3, 2, 1}: the 16 lanes of every ds_read_b128 group (rows l15, chunk q4) hit 16 distinct slots.
+constexpr int T256_HALF_A = 256 * 32 * 2;                  // 16 KB
+constexpr int T256_HALF_B = 128 * 32 * 2;                  // 8 KB per limb
+constexpr int T256_HALF = T256_HALF_A + 2 * T256_HALF_B;   // 32 KB
+__device__ __forceinline__ int ring_g(int j) { return (4 - j) & 3; }
+
+template <int TM, int AL, int EPI>
+__device__ __forceinline__ void t256_tile_ring(const GemmF16Args& g, char* smem, const int bm, const int bn, const int w, const int lane,
+                                               unsigned long long* st_sum, int& stage_ctr) {
+  constexpr int WROWS = TM * 16;
+  const int wm = w >> 1, wn = w & 1;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int nl = (g.Rp / GK) * 2;
+  const int T = nl + AL * (g.Kp / GK);                      // 64-deep stages; half stages u = 2 * t + h
+  const int U = 2 * T;
+  const float lora_to_base = (AL == 2) ? g.xscale[0] : 1.f;
+  const float out_scale = (AL == 2) ? g.xscale[1] : 1.f;
+
+  // a copy piece = 1 KB = 16 rows x 64 B: lane L -> row L >> 2, chunk position L & 3, source chunk (L & 3) ^ g[L >> 4]
+  // A: 2 * TM pieces (wave w owns TM / 2 ... of them), each B limb 8 pieces (2 per wave)
+  const int prow = lane >> 2;
+  const int pcol = ((lane & 3) ^ ring_g(lane >> 4)) * 8;    // elements
+  auto issue = [&](int u) {
+    if ((T256_DIAG & 1) && u > 1) return;
+    const int t = u >> 1, h = u & 1;
+    char* slot = smem + (u & 1) * T256_HALF;
+    const _Float16 *A, *Bh, *Bl; int ld, k0; bool two;
+    if (t < nl) {
+      const int which = t & 1;
+      A = which ? g.tlo : g.thi; ld = g.Rp; Bh = g.Bhi; Bl = g.Blo; k0 = (t >> 1) * GK; two = !which;
+    } else if (AL == 1) {
+      A = g.qx; ld = g.Kp; Bh = g.Whi; Bl = g.Wlo; k0 = (t - nl) * GK; two = true;
+    } else {
+      const int tb = t - nl, which = tb & 1;
+      A = which ? g.xl : g.qx; ld = g.Kp; Bh = g.Whi; Bl = g.Wlo; k0 = (tb >> 1) * GK; two = !which;
     }
-  }
-  {
-    char* eb = smem + w * (T256_STAGE / 4);                  // 16 KB per wave: four 16 x 32 blocks per round
-    const int c4 = (lane & 7) * 4;
-    const bool interior = (bm + 32 * TM <= g.M) && (bn + GN <= g.N);
+    k0 += 32 * h;
+    const unsigned v = (unsigned)(prow * ld + pcol) * 2u;
+    constexpr int AP = TM / 2;                               // A pieces per wave (16 rows each)
+    const char* Ab = reinterpret_cast<const char*>(A + (int64_t)bm * ld + k0) + (int64_t)(AP * w) * 32 * ld;
+    const char* Bhb = reinterpret_cast<const char*>(Bh + (int64_t)bn * ld + k0) + (int64_t)(2 * w) * 32 * ld;
+    const char* Blb = reinterpret_cast<const char*>(Bl + (int64_t)bn * ld + k0) + (int64_t)(2 * w) * 32 * ld;
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int n = bn + wn * 64 + tn * 32 + c4;
-      const bool n_ok = n < g.N;
-      const float4 rs = ep_rs[tn], bv = ep_bv[tn];
+    for (int i = 0; i < AP; ++i) glds16(Ab + (int64_t)i * 32 * ld + v, slot + (AP * w + i) * 1024);
 #pragma unroll
-      for (int t4 = 0; t4 < TM; t4 += 4) {
+    for (int i = 0; i < 2; ++i) {
+      glds16(Bhb + (int64_t)i * 32 * ld + v, slot + T256_HALF_A + (2 * w + i) * 1024);
+      if (two) glds16(Blb + (int64_t)i * 32 * ld + v, slot + T256_HALF_A + T256_HALF_B + (2 * w + i) * 1024);
+    }
+  };
+
+  const int fpos = (q4 ^ ring_g((l15 >> 2) & 3)) * 16;
+  const int fa_off = (wm * WROWS + l15) * 64 + fpos;
+  const int fb_off = T256_HALF_A + (wn * 64 + l15) * 64 + fpos;
+  f32x4 acc[TM][4];
 #pragma unroll
-        for (int tq = 0; tq < 4; ++tq)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            *reinterpret_cast<float*>(eb + tq * EPI_WAVE + (4 * q4 + e) * 144 + l15 * 4) = acc[t4 + tq][2 * tn][e];
-            *reinterpret_cast<float*>(eb + tq * EPI_WAVE + (4 * q4 + e) * 144 + (16 + l15) * 4) = acc[t4 + tq][2 * tn + 1][e];
-          }
-        float4 v[8];
+    for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(eb + (j >> 1) * EPI_WAVE + ((j & 1) * 8 + (lane >> 3)) * 144 + c4 * 4);
+      for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
+
+  auto half_stage = [&](int u, bool two) {
+#if T256_PRIO_PERIOD > 0
+    if (stage_ctr % T256_PRIO_PERIOD == 0) {
+      if ((stage_ctr / T256_PRIO_PERIOD) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
+    ++stage_ctr;
+#endif
+#if T256_DIAG & 8
+    const unsigned long long s0 = __builtin_readcyclecounter();
+#endif
+    __syncthreads();                                         // my copies of u have landed, my reads of the other slot are done; barrier
+#if T256_DIAG & 8
+    const unsigned long long s1 = __builtin_readcyclecounter();
+#endif
+    if (u + 1 < U) issue(u + 1);
+#if T256_DIAG & 8
+    const unsigned long long s2 = __builtin_readcyclecounter();
+#endif
+    if (!(T256_DIAG & 2)) {
+      const char* slot = smem + (u & 1) * T256_HALF;
+      f16x8 bh[4], bl[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int m = bm + wm * WROWS + (t4 + (j >> 1)) * 16 + (j & 1) * 8 + (lane >> 3);
-          float4 o;
-          o.x = v[j].x * rs.x + bv.x; o.y = v[j].y * rs.y + bv.y; o.z = v[j].z * rs.z + bv.z; o.w = v[j].w * rs.w + bv.w;
-          if (EPI == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
-          float* dst = g.y + (int64_t)m * g.N + n;
-          if (T256_DIAG & 4) { if (o.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }
-          else if (interior) *reinterpret_cast<float4*>(dst) = o;
-          else if (n_ok && m < g.M) *reinterpret_cast<float4*>(dst) = o;
+      for (int tn = 0; tn < 4; ++tn) {
+        bh[tn] = *reinterpret_cast<const f16x8*>(slot + fb_off + tn * 1024);
+        if (two) bl[tn] = *reinterpret_cast<const f16x8*>(slot + fb_off + T256_HALF_B + tn * 1024);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const f16x8 a = *reinterpret_cast<const f16x8*>(slot + fa_off + tm * 1024);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh[tn], acc[tm][tn], 0, 0, 0);
+          if (two) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl[tn], acc[tm][tn], 0, 0, 0);
         }
       }
     }
+#if T256_DIAG & 8
+    asm volatile("s_nop 0" :: "v"(acc[TM - 1][3][0]), "v"(acc[0][0][0]) : "memory");
+    const unsigned long long s3 = __builtin_readcyclecounter();
+    st_sum[0] += s1 - s0; st_sum[1] += s3 - s2; st_sum[3] += s2 - s1;
+#endif
+  };
+
+  issue(0);
+  for (int t = 0; t < nl; ++t) { const bool two = !(t & 1); half_stage(2 * t, two); half_stage(2 * t + 1, two); }
+  if (nl > 0) {                                              // LoRA partial sums -> units of the base sum: * 2^-g[m]
+    f32x4 riv[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) riv[tm] = *reinterpret_cast<const f32x4*>(g.rowinv + bm + wm * WROWS + tm * 16 + 4 * q4);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float ri = riv[tm][e];
+        if (AL == 2) ri *= lora_to_base;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn][e] *= ri;
+      }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the slices are done with: the next tile's copies may land on them
-  __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+  if (AL == 1) {
+    for (int t = nl; t < T; ++t) { half_stage(2 * t, true); half_stage(2 * t + 1, true); }
+  } else {
+    for (int t = nl; t < T; ++t) { const bool two = !((t - nl) & 1); half_stage(2 * t, two); half_stage(2 * t + 1, two); }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave has read its last fragments: the buffer is free
+#if T256_DIAG & 8
+  const unsigned long long e0 = __builtin_readcyclecounter();
+#endif
+  t256_epilogue<TM, AL, EPI>(g, smem, acc, bm, bn, w, lane, out_scale);
 #if T256_DIAG & 8
   st_sum[4] += __builtin_readcyclecounter() - e0;
 #endif
@@ -257,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_t256_kernel(GemmF16Args g, 
     const int in_band = wgid - band * GROUP_M * g.tiles_n;
     const int bm = (band * GROUP_M + in_band % band_rows) * 256;
     const int bn = (in_band / band_rows) * GN;
-    t256_tile<8, AL, EPI>(g, smem, bm, bn, w, lane, st_sum, stage_ctr);
+    if (T256_RING) t256_tile_ring<8, AL, EPI>(g, smem, bm, bn, w, lane, st_sum, stage_ctr); else t256_tile<8, AL, EPI>(g, smem, bm, bn, w, lane, st_sum, stage_ctr);
   }
   // half tiles: workgroups that got one whole tile fewer than the others take two halves first, the rest is dealt round robin
   {
@@ -268,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x2_t256_kernel(GemmF16Args g, 
     auto half = [&](int h) {
       const int bm = pl.full_bands * 256 + (h % hrows) * 128;
       const int bn = (h / hrows) * GN;
-      t256_tile<4, AL, EPI>(g, smem, bm, bn, w, lane, st_sum, stage_ctr);
+      if (T256_RING) t256_tile_ring<4, AL, EPI>(g, smem, bm, bn, w, lane, st_sum, stage_ctr); else t256_tile<4, AL, EPI>(g, smem, bm, bn, w, lane, st_sum, stage_ctr);
     };
     if (rem && b >= rem) {
 #pragma unroll 1
