@@ -16,6 +16,8 @@ f16 MFMA contraction as part1's base term, with no LoRA stages at all.
 import ctypes
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -435,7 +437,8 @@ class CPTLinear(nn.Module):
         self._bwd_gemm = None
         self._gemm_events = None
         self._last_path = None
-        self.cache_operands = True          # eval mode: reuse the prepared weight while W, A, B and the scales are unchanged
+        # eval mode: reuse the prepared weight while W, A, B and the scales are unchanged (SPQ_CACHE_OPERANDS=0: never)
+        self.cache_operands = os.environ.get("SPQ_CACHE_OPERANDS", "1") != "0"
 
     def set_precision(self, num_bits: int):
         if num_bits not in self.bit_widths:

@@ -206,7 +206,9 @@ class SPLinearWithLoRA(nn.Module):
 
         # --- not part of the reference surface -----------------------------------------------------------
         self.operand_path = _lib.PATH_AUTO        # enum spq_path; AUTO picks the fastest valid one
-        self.cache_operands = True                # reuse prepared operands in eval mode (see _operands)
+        # reuse prepared operands in eval mode (see _operands); SPQ_CACHE_OPERANDS=0 turns the reuse off process-wide
+        # (every forward re-quantises, as the reference does) for code that writes weights through `.data` in place
+        self.cache_operands = os.environ.get("SPQ_CACHE_OPERANDS", "1") != "0"
         self._prepared = {}
         self._gemm_events = None                  # (hipEvent_t, hipEvent_t) around the dominant kernel, for bench.py
         self.backward_limbs = True                # d/dx on the f16 MFMA limb kernel (False: fp32 MFMA kernel)
