@@ -244,6 +244,21 @@ typedef struct spq_fwd_args {
   const float* ln_weight;
   const float* ln_bias;
   float ln_eps;
+  /* F16X2 / F16X3 paths, optional levels-out store (second half: "GELU -> input quantizer of the next linear",
+   * models_sp.py:124-128 / cpt_model.py:196-198): with out_levels set the contraction's store ALSO writes the NEXT quantized
+   * layer's activation operand -- fp16 integer levels clamp(round(v / out_scale[n]), +-(2^(out_bits-1) - 1)) of the value v
+   * it stores (after `epilogue`), exactly what quantization_methods.py:14-15 computes from y -- to
+   * out_levels[m * out_levels_ld + n].  The consumer then runs with stage = SPQ_STAGE_CONTRACTION on a workspace that starts
+   * with that level matrix (row pitch ceil(N/64)*64 = its padded K), and with y = NULL here the fp32 activation is never
+   * written or re-read.  Exact wherever the consumer's LoRA branch does not read the RAW activation: r = 0, or part2's
+   * CPTLinear whose branch consumes FQ(x) and is folded into the weight (cpt_model.py:112); part1's branch reads the raw
+   * x (lora.py:149) and still needs y.  Needs the 128x128 contraction kernel (the default), N % 64 == 0, a symmetric
+   * min-max consumer of 2..12 bits; out_scale has N entries (out_scale_per_channel) or one.  SPQ_ERR_UNSUPPORTED otherwise. */
+  void* out_levels;
+  int64_t out_levels_ld;
+  const float* out_scale;
+  int out_scale_per_channel;
+  int out_bits;
 } spq_fwd_args;
 
 size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path);

@@ -70,7 +70,9 @@ extern "C" int spq_linear_lora_fwd(const spq_fwd_args* a, spq_stream_t stream) {
   SPQ_REQUIRE(a, "spq_linear_lora_fwd: null args");
   SPQ_REQUIRE(a->M > 0 && a->K > 0 && a->N > 0 && a->r >= 0, "spq_linear_lora_fwd: bad shape M=%lld K=%lld N=%lld r=%lld",
               (long long)a->M, (long long)a->K, (long long)a->N, (long long)a->r);
-  SPQ_REQUIRE(a->x && a->w_prep && a->y, "spq_linear_lora_fwd: null operand");
+  SPQ_REQUIRE((a->x || a->stage == SPQ_STAGE_CONTRACTION) && a->w_prep && (a->y || a->out_levels), "spq_linear_lora_fwd: null operand");
+  SPQ_REQUIRE(!a->out_levels || (a->path == SPQ_PATH_F16X2 || a->path == SPQ_PATH_F16X3),
+              "spq_linear_lora_fwd: the levels-out store exists on the F16X2 / F16X3 operand paths only");
   SPQ_REQUIRE(!a->quantize_input || (a->sx && a->zx), "spq_linear_lora_fwd: input scale missing");
   SPQ_REQUIRE(!a->quantize_input || (a->bits >= 1 && a->bits <= 24), "spq_linear_lora_fwd: bits %d outside [1,24]", a->bits);
   SPQ_REQUIRE(a->r == 0 || (a->a_prep && (a->b_prep || a->t_out)), "spq_linear_lora_fwd: LoRA operands missing");

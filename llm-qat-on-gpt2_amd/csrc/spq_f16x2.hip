@@ -1390,6 +1390,8 @@ struct GemmF16Args {
   const _Float16* xl;
   const float* xscale;                      // device {2^G, 2^-G}; null when a_limbs == 1
   int a_limbs;
+  // levels-out store (spq_fwd_args::out_levels; gemm_f16x2_t128_kernel<.., LV = 1> only): y may be null then
+  _Float16* lv; const float* lv_scale; int lv_ld, lv_pc; float lv_qhi;
 };
 
 // ---- LDS: two 64-deep stage buffers (A 256x64 f16 = 32 KB, B hi/lo 128x64 f16 = 16 KB each) + a dedicated
@@ -1935,7 +1937,10 @@ constexpr int T128_LDS = T128_DEFER ? T128_STAGE : T128_STAGE + 4 * EPI_WAVE;
 #ifndef T128_GROUP_M
 #define T128_GROUP_M 8      // measured at the headline shape: 8 -> 81.5 us, 16 -> 82.9, 32 -> 84.5, 4 -> 84.5
 #endif
-template <int AL, int EPI>
+// LV = 1: the store also writes the next layer's level matrix (GemmF16Args::lv): q = clamp(rint(o / s[n]), +-qhi) of the very
+// value o it stores -- IEEE division, round half to even, as quantization_methods.py:14-15 -- four fp16 levels (8 B) per lane
+// next to (or, with g.y null, instead of) the 16 B of fp32.
+template <int AL, int EPI, int LV = 0>
 __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2127,11 +2132,18 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
     }
     // epilogue operands: fetched here, not at the tile's start (16 registers that three waves per SIMD do not leave through
     // the stage loop); the CU's other workgroups cover the load's latency
-    float4 ep_rs[2], ep_bv[2];
+    float4 ep_rs[2], ep_bv[2], ep_ls[2];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
       const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
       ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
+      if (LV) {
+        ep_ls[tn] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (n < g.N) {
+          if (g.lv_pc) ep_ls[tn] = *reinterpret_cast<const float4*>(g.lv_scale + n);
+          else { const float s1 = g.lv_scale[0]; ep_ls[tn] = make_float4(s1, s1, s1, s1); }
+        }
+      }
       if (n < g.N) {
         ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);
         if (AL == 2) { ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale; }
@@ -2163,6 +2175,14 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
             o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
             if (EPI == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
             float* dst = g.y + (int64_t)m * g.N + n;
+            if (LV) {
+              const float4 ls = ep_ls[tn];
+              const float qhi = g.lv_qhi;
+              if (interior || (n_ok && m < g.M))
+                store_levels4(g.lv, (int64_t)m * g.lv_ld + n, minmax_level<true>(o.x, ls.x, 0.f, -qhi, qhi), minmax_level<true>(o.y, ls.y, 0.f, -qhi, qhi),
+                              minmax_level<true>(o.z, ls.z, 0.f, -qhi, qhi), minmax_level<true>(o.w, ls.w, 0.f, -qhi, qhi), 0);
+              if (!g.y) continue;
+            }
             if (T128_DIAG & 4) { if (o.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }   // (non-temporal stores: no change, 79.3 vs 79.2 us)
             else if (interior) *reinterpret_cast<float4*>(dst) = o;
             else if (n_ok && m < g.M) *reinterpret_cast<float4*>(dst) = o;
@@ -2862,6 +2882,17 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   g.M = (int)a->M; g.N = (int)a->N; g.Kp = (int)L.Kp; g.Rp = lora_up ? (int)L.Rp : 0;
   g.tiles_m = (int)(L.Mp / GM); g.tiles_n = (int)(P.Np / GN); g.dbg = nullptr;
   g.xl = x.xl; g.xscale = a->x_limb_scale; g.a_limbs = x3 ? 2 : 1;
+  g.lv = (_Float16*)a->out_levels; g.lv_scale = a->out_scale; g.lv_ld = (int)a->out_levels_ld; g.lv_pc = a->out_scale_per_channel;
+  g.lv_qhi = 0.f;
+  if (a->out_levels) {
+    if (!(a->out_scale && a->out_bits >= 2 && a->out_bits <= 12 && (a->N % 64) == 0 && a->out_levels_ld >= a->N && (a->out_levels_ld % 4) == 0 &&
+          aligned16(a->out_levels) && aligned16(a->out_scale))) {
+      set_error("spq_linear_lora_fwd: levels-out store needs out_scale, 2..12 out_bits, N %% 64 == 0 and a 16-B aligned level matrix with "
+                "row pitch >= N (got bits=%d N=%lld ld=%lld)", a->out_bits, (long long)a->N, (long long)a->out_levels_ld);
+      return SPQ_ERR_UNSUPPORTED;
+    }
+    g.lv_qhi = (float)((1 << (a->out_bits - 1)) - 1);
+  }
   if (AttrOnce once(3); once.first) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_f16x2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        GEMM_LDS);
@@ -2874,6 +2905,10 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
   }
   if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
   // default: the 16x16x32 variant (measured 85 us vs 90 us for the 32x32x16 one on the headline shape, same cycles per
@@ -2900,13 +2935,20 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     const int ntiles = 2 * g.tiles_m * g.tiles_n;
     const unsigned cus2 = T128_WGS * gemm_grid(1 << 30);
     const unsigned grid128 = (unsigned)ntiles < cus2 ? (unsigned)ntiles : cus2;
-    if (x3 && gelu) gemm_f16x2_t128_kernel<2, 1><<<grid128, 256, T128_LDS, st>>>(g);
+    if (g.lv) {
+      if (x3 && gelu) gemm_f16x2_t128_kernel<2, 1, 1><<<grid128, 256, T128_LDS, st>>>(g);
+      else if (x3) gemm_f16x2_t128_kernel<2, 0, 1><<<grid128, 256, T128_LDS, st>>>(g);
+      else if (gelu) gemm_f16x2_t128_kernel<1, 1, 1><<<grid128, 256, T128_LDS, st>>>(g);
+      else gemm_f16x2_t128_kernel<1, 0, 1><<<grid128, 256, T128_LDS, st>>>(g);
+    }
+    else if (x3 && gelu) gemm_f16x2_t128_kernel<2, 1><<<grid128, 256, T128_LDS, st>>>(g);
     else if (x3) gemm_f16x2_t128_kernel<2, 0><<<grid128, 256, T128_LDS, st>>>(g);
     else if (gelu) gemm_f16x2_t128_kernel<1, 1><<<grid128, 256, T128_LDS, st>>>(g);
     else gemm_f16x2_t128_kernel<1, 0><<<grid128, 256, T128_LDS, st>>>(g);
     if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
     return check_launch("spq_linear_lora_fwd(gemm_t128)");
   }
+  if (g.lv) { set_error("spq_linear_lora_fwd: the levels-out store needs the 128x128 contraction kernel (unset SPQ_GEMM_T128 / SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
   const unsigned grid = gemm_grid(g.tiles_m * g.tiles_n);
   if (mfma16 && x3 && gelu) gemm_f16x2_s16_kernel<0, 2, 1><<<grid, GEMM_THREADS, GEMM_LDS, st>>>(g);
   else if (mfma16 && x3) gemm_f16x2_s16_kernel<0, 2><<<grid, GEMM_THREADS, GEMM_LDS, st>>>(g);
