@@ -368,32 +368,50 @@ class _QuantGemm:
         self.a_limb_scale = _limb_scale(ql) if (want_aq_t and r and ql is not None and ql.active()) else None
         self.sig = None if sig is None else (sig, path, qi._epoch, qi.num_bits)
 
-    def run(self, x2, bias, q, quantize, want_t=False, gemm_events=None):
-        M, K = x2.shape
+    def run(self, x2, bias, q, quantize, want_t=False, gemm_events=None, epilogue=0, levels_out=None, levels_in=None, M=None):
+        """``levels_out`` = (buffer, row pitch, next input quantizer): the store writes the next layer's level matrix instead of
+        fp32 (spq_fwd_args.out_levels; returns None).  ``levels_in`` = a workspace-sized buffer whose head is this layer's own
+        level matrix, written by the producer: only the contraction runs (x2 is not read and may be None)."""
+        if levels_in is not None:
+            K = self.w_eff.shape[1]
+            dev = levels_in.device
+        else:
+            M, K = x2.shape
+            dev = x2.device
         N = self.w_eff.shape[0]
-        dev = x2.device
         lib = _lib.load()
         path = self.path
         r = self.r if want_t else 0
         if r > 128 or (r > 0 and path != _lib.PATH_F32 and r > 64):
             raise RuntimeError("the LoRA-down product of the activation pass needs rank <= 64")
         t = torch.empty(M, r, dtype=torch.float32, device=dev) if r else None
-        y = torch.empty(M, N, dtype=torch.float32, device=dev)
+        y = None if levels_out is not None else torch.empty(M, N, dtype=torch.float32, device=dev)
         st = _lib.stream_ptr(dev)
         sx = q.scale if quantize else None
         zx = q.zero_point if quantize else None
         if quantize and sx.numel() not in (1, K):
             raise RuntimeError(f"input scale of shape {tuple(sx.shape)} does not fit input features {K}")
-        ws = _lib.workspace(dev, lib.spq_fwd_workspace_bytes(M, K, N, r, path))
+        need = lib.spq_fwd_workspace_bytes(M, K, N, r, path)
+        if levels_in is not None:
+            if r or path != _lib.PATH_F16X2 or levels_in.numel() < need:
+                raise RuntimeError("levels_in needs the F16X2 operand path without a LoRA-down product and a workspace-sized buffer")
+            ws = levels_in
+        else:
+            ws = _lib.workspace(dev, need)
         f32 = path == _lib.PATH_F32
+        lv_buf, lv_ld, lv_q = levels_out if levels_out is not None else (None, 0, None)
         limb_scale = _limb_scale(q) if path == _lib.PATH_F16X3 else None
         args = _lib.FwdArgs(
             M=M, K=K, N=N, r=r, bits=int(q.num_bits) if quantize else 32,
             qtype=_lib.QTYPE_CODE_CPT.get(q.quantizer_type, 0), symmetric=1 if q.symmetric else 0,
             quantize_input=1 if quantize else 0, x_per_channel=1 if (quantize and sx.numel() > 1) else 0, path=path,
-            x=x2.data_ptr(), sx=_lib.ptr(sx), zx=_lib.ptr(zx), x_limb_scale=_lib.ptr(limb_scale),
+            x=x2.data_ptr() if x2 is not None else None, sx=_lib.ptr(sx), zx=_lib.ptr(zx), x_limb_scale=_lib.ptr(limb_scale),
             w_prep=self.w_eff.data_ptr() if f32 else self.w.data_ptr(), w_rowscale=None if f32 else self.rowscale.data_ptr(),
-            bias=_lib.ptr(bias), a_prep=self.aq_t.data_ptr() if r else None, b_prep=None, lora_scaling=0.0, y=y.data_ptr(),
+            bias=_lib.ptr(bias), a_prep=self.aq_t.data_ptr() if r else None, b_prep=None, lora_scaling=0.0, y=_lib.ptr(y),
+            stage=_lib.STAGE_CONTRACTION if levels_in is not None else _lib.STAGE_ALL, epilogue=epilogue,
+            out_levels=_lib.ptr(lv_buf), out_levels_ld=lv_ld, out_scale=_lib.ptr(lv_q.scale) if lv_q is not None else None,
+            out_scale_per_channel=1 if (lv_q is not None and lv_q.scale.numel() > 1) else 0,
+            out_bits=int(lv_q.num_bits) if lv_q is not None else 0,
             workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
             ev_gemm_begin=gemm_events[0] if gemm_events else None, ev_gemm_end=gemm_events[1] if gemm_events else None,
             t_out=_lib.ptr(t), lora_on_fq_input=1, a_limb_scale=_lib.ptr(self.a_limb_scale) if r else None)
@@ -401,6 +419,59 @@ class _QuantGemm:
             rc = lib.spq_linear_lora_fwd(ctypes.byref(args), st)
         _lib.check(rc, "spq_linear_lora_fwd(cpt)")
         return (y, t) if r else y
+
+
+def _chain_ready(layer, bits):
+    """the fused pair needs both layers quantizing at a calibrated width, nothing recording statistics"""
+    qi, qw = layer.quantizer_input, layer.quantizer_weight
+    if layer.current_bits != bits or bits >= 32 or layer.calibration_mode:
+        return False
+    use_lora = layer.shared_lora.lora_A is not None
+    qs = [qi, qw] + ([layer.lora_weight_quantizers[f'{bits}bit']] if use_lora else [])
+    return all(q.num_bits == bits and not q.collecting_stats and bits in q.calibrated_bits for q in qs)
+
+
+def cpt_mlp_forward(fc_in, fc_out, x, fuse=True):
+    """``fc_out(F.gelu(fc_in(x)))`` -- CPTBlock's feed-forward (cpt_model.py:196-198) -- with the activation between the two
+    layers never stored in fp32 (second half): fc_in's contraction applies the exact-erf GELU in its store and
+    writes fc_out's INPUT LEVELS clamp(round(h / s_in[n]), +-(2^(b-1) - 1)) as fp16 straight into fc_out's activation operand;
+    fc_out then runs its contraction only.  This is exact for a CPTLinear consumer: its LoRA branch reads FQ(x)
+    (cpt_model.py:112) and is folded into the weight, so nothing downstream needs h itself (part1's branch reads the raw
+    activation, lora.py:149, which is why SPMLP keeps the fp32 store).  Taken in no-grad forwards when both layers quantize
+    at a calibrated width, fc_out's input quantizer is symmetric min-max of at most 12 bits and 4 n_embd is a multiple of 64;
+    anything else runs the two layers one after the other (same result: the levels are the same numbers either way)."""
+    bits = fc_in.current_bits
+    qi2 = fc_out.quantizer_input
+    ok = (fuse and not torch.is_grad_enabled() and x.is_cuda and x.numel() > 0 and _chain_ready(fc_in, bits) and _chain_ready(fc_out, bits)
+          and qi2.quantizer_type == 'minmax' and qi2.symmetric and 2 <= bits <= 12 and fc_in.out_features % 64 == 0
+          and fc_in.out_features == fc_out.in_features and _MFMA16 and os.environ.get("SPQ_GEMM_T128", "1") != "0"
+          and _QuantGemm.path_for(fc_in.quantizer_input, fc_in.out_features, True) != _lib.PATH_F32)
+    if not ok:
+        return fc_out(F.gelu(fc_in(x)))
+    _lib.check_device(x.device)
+    lib = _lib.load()
+    dev = x.device
+    lead = tuple(x.shape[:-1])
+    x2 = x.detach().contiguous().float().view(-1, fc_in.in_features)
+    M, H = x2.shape[0], fc_in.out_features
+    # fc_out's activation operand: a buffer of its own (the shared workspace holds fc_in's operands while fc_in runs)
+    need = lib.spq_fwd_workspace_bytes(M, H, fc_out.out_features, 0, _lib.PATH_F16X2)
+    buf = getattr(fc_out, "_levels_in", None)
+    if buf is None or buf.numel() < need or buf.device != dev:
+        buf = torch.empty(need, dtype=torch.uint8, device=dev)
+        fc_out._levels_in = buf
+    for layer, qi in ((fc_in, fc_in.quantizer_input), (fc_out, qi2)):
+        use_lora = layer.shared_lora.lora_A is not None
+        path = _QuantGemm.path_for(qi, layer.out_features, True)
+        sig = layer._weights_sig(use_lora) if (layer.cache_operands and not layer.training) else None
+        gm = layer._gemm
+        if not (sig is not None and gm.sig == (sig, path, qi._epoch, qi.num_bits)):
+            gm.prepare(layer, use_lora, path, qi, True, sig=sig)
+        layer._last_path = gm.path
+    fc_in._gemm.run(x2, fc_in.linear.bias, fc_in.quantizer_input, True, gemm_events=fc_in._gemm_events, epilogue=_lib.EPILOGUE_GELU,
+                    levels_out=(buf, H, qi2))
+    y = fc_out._gemm.run(None, fc_out.linear.bias, qi2, True, gemm_events=fc_out._gemm_events, levels_in=buf, M=M)
+    return y.view(*lead, fc_out.out_features)
 
 
 def _sig(t):

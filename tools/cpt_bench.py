@@ -42,3 +42,35 @@ for (M, K, N, r, bits, qt) in [(8192, 768, 3072, 16, 4, 'minmax'), (8192, 768, 3
     t_train = timeit(step, 30)
     print(f'CPT {qt}{bits} M={M} K={K} N={N} r={r} path={PATHN[m._last_path]}: eval {t_eval*1e3:.4f} ms ({flop/t_eval/1e12:.0f} TFLOP/s), '
           f'weights re-quantized every call {t_requant*1e3:.4f} ms ({flop/t_requant/1e12:.0f} TFLOP/s), fwd+bwd {t_train*1e3:.3f} ms', flush=True)
+
+
+# CPTBlock's feed-forward fc_out(gelu(fc_in(x))) (cpt_model.py:196-198): two layers + stock gelu against the fused pair
+# (GELU in fc_in's store, fc_out's input levels written by that store, no fp32 activation: cpt_mlp_forward)
+import torch.nn.functional as F
+for (M, E, bits) in [(8192, 768, 4), (32768, 768, 4), (8192, 768, 8), (8192, 1024, 4)]:
+    H, r = 4 * E, 16
+    layers = []
+    for (K, N) in ((E, H), (H, E)):
+        W, bias, A, B, x0, x1 = C.make_cpt_workload(256, K, N, r, seed=1, batch=4)
+        m = pkg.CPTLinear(K, N, bit_widths=[bits, 32], quantizer_per_bit={bits: 'minmax', 32: None}, shared_lora_rank=r, shared_lora_alpha=32)
+        with torch.no_grad():
+            m.linear.weight.copy_(W); m.linear.bias.copy_(bias); m.shared_lora.lora_A.copy_(A); m.shared_lora.lora_B.copy_(B)
+        layers.append(m.to(dev).eval())
+    fc_in, fc_out = layers
+    torch.manual_seed(0)
+    xs = [torch.randn(8, M // 8, E, device=dev) for _ in range(2)]
+    pkg.calibrate_cpt_layer(fc_in, bits, xs)
+    with torch.no_grad():
+        hs = [F.gelu(fc_in(x)) for x in xs]
+    pkg.calibrate_cpt_layer(fc_out, bits, hs)
+    del hs
+    x = xs[0]
+    flop = 2 * M * 2 * (E * H + E * r + r * H)
+    with torch.no_grad():
+        t_two = timeit(lambda: fc_out(F.gelu(fc_in(x))), 30)
+        t_fused = timeit(lambda: pkg.cpt_mlp_forward(fc_in, fc_out, x), 30)
+        for l in layers: l.cache_operands = False
+        t_two_rq = timeit(lambda: fc_out(F.gelu(fc_in(x))), 30)
+        t_fused_rq = timeit(lambda: pkg.cpt_mlp_forward(fc_in, fc_out, x), 30)
+    print(f'CPT feed-forward minmax{bits} {M} tokens E={E}: two layers + gelu {t_two*1e3:.4f} ms ({flop/t_two/1e12:.0f} TFLOP/s), fused pair '
+          f'{t_fused*1e3:.4f} ms ({flop/t_fused/1e12:.0f} TFLOP/s); weights re-quantized every call: {t_two_rq*1e3:.4f} vs {t_fused_rq*1e3:.4f} ms', flush=True)
