@@ -259,6 +259,16 @@ typedef struct spq_fwd_args {
   const float* out_scale;
   int out_scale_per_channel;
   int out_bits;
+  /* ... for ANY consumer quantizer (log, asymmetric, 13..24 bit: the consumer's SPQ_PATH_F16X3 operand): with out_levels_lo set
+   * the store writes the two fp16 limbs of FQ(v) * 2^G -- hi to out_levels, lo to out_levels_lo (the consumer workspace's second
+   * plane, ceil(M/256)*256 * ceil(N/64)*64 halves behind the first) -- with FQ the consumer's quantize-dequantize
+   * (out_qtype / out_symmetric / out_bits 1..24, out_scale and out_zero both with N entries or one; log: range and min) and
+   * out_limb_scale the consumer's device {2^G, 2^-G} (its x_limb_scale). */
+  void* out_levels_lo;
+  const float* out_zero;
+  int out_qtype;
+  int out_symmetric;
+  const float* out_limb_scale;
 } spq_fwd_args;
 
 size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path);

@@ -54,7 +54,8 @@ class FwdArgs(C.Structure):
                 ("y", _p), ("workspace", _p), ("workspace_bytes", _sz),
                 ("ev_gemm_begin", _p), ("ev_gemm_end", _p), ("t_out", _p), ("lora_on_fq_input", _int), ("stage", _int), ("epilogue", _int), ("a_limb_scale", _p),
                 ("prepare", C.POINTER(PrepareArgs)), ("ln_weight", _p), ("ln_bias", _p), ("ln_eps", _f),
-                ("out_levels", _p), ("out_levels_ld", _i64), ("out_scale", _p), ("out_scale_per_channel", _int), ("out_bits", _int)]
+                ("out_levels", _p), ("out_levels_ld", _i64), ("out_scale", _p), ("out_scale_per_channel", _int), ("out_bits", _int),
+                ("out_levels_lo", _p), ("out_zero", _p), ("out_qtype", _int), ("out_symmetric", _int), ("out_limb_scale", _p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/spq.h declares (tests/test_cabi.py checks).

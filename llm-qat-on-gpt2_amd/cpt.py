@@ -393,13 +393,20 @@ class _QuantGemm:
             raise RuntimeError(f"input scale of shape {tuple(sx.shape)} does not fit input features {K}")
         need = lib.spq_fwd_workspace_bytes(M, K, N, r, path)
         if levels_in is not None:
-            if r or path != _lib.PATH_F16X2 or levels_in.numel() < need:
-                raise RuntimeError("levels_in needs the F16X2 operand path without a LoRA-down product and a workspace-sized buffer")
+            if r or path not in (_lib.PATH_F16X2, _lib.PATH_F16X3) or levels_in.numel() < need:
+                raise RuntimeError("levels_in needs an F16 operand path without a LoRA-down product and a workspace-sized buffer")
             ws = levels_in
         else:
             ws = _lib.workspace(dev, need)
         f32 = path == _lib.PATH_F32
         lv_buf, lv_ld, lv_q = levels_out if levels_out is not None else (None, 0, None)
+        lv_lo = lv_zero = lv_limb = None
+        if lv_q is not None and _QuantGemm.path_for(lv_q, 4, True) == _lib.PATH_F16X3:
+            # any other consumer quantizer: two fp16 limbs of FQ(v) * 2^G; the second plane sits where the consumer's workspace
+            # keeps it (spq_f16x2.hip make_layout: off_xl = Mp * Kp * 2 bytes, Mp = M rounded up to 256, Kp = the row pitch)
+            Mp = (M + 255) // 256 * 256
+            lv_lo = lv_buf.data_ptr() + Mp * lv_ld * 2
+            lv_zero, lv_limb = lv_q.zero_point, _limb_scale(lv_q)
         limb_scale = _limb_scale(q) if path == _lib.PATH_F16X3 else None
         args = _lib.FwdArgs(
             M=M, K=K, N=N, r=r, bits=int(q.num_bits) if quantize else 32,
@@ -412,6 +419,8 @@ class _QuantGemm:
             out_levels=_lib.ptr(lv_buf), out_levels_ld=lv_ld, out_scale=_lib.ptr(lv_q.scale) if lv_q is not None else None,
             out_scale_per_channel=1 if (lv_q is not None and lv_q.scale.numel() > 1) else 0,
             out_bits=int(lv_q.num_bits) if lv_q is not None else 0,
+            out_levels_lo=lv_lo, out_zero=_lib.ptr(lv_zero), out_qtype=_lib.QTYPE_CODE_CPT.get(lv_q.quantizer_type, 0) if lv_q is not None else 0,
+            out_symmetric=1 if (lv_q is not None and lv_q.symmetric) else 0, out_limb_scale=_lib.ptr(lv_limb),
             workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
             ev_gemm_begin=gemm_events[0] if gemm_events else None, ev_gemm_end=gemm_events[1] if gemm_events else None,
             t_out=_lib.ptr(t), lora_on_fq_input=1, a_limb_scale=_lib.ptr(self.a_limb_scale) if r else None)
@@ -434,18 +443,20 @@ def _chain_ready(layer, bits):
 def cpt_mlp_forward(fc_in, fc_out, x, fuse=True):
     """``fc_out(F.gelu(fc_in(x)))`` -- CPTBlock's feed-forward (cpt_model.py:196-198) -- with the activation between the two
     layers never stored in fp32 (second half): fc_in's contraction applies the exact-erf GELU in its store and
-    writes fc_out's INPUT LEVELS clamp(round(h / s_in[n]), +-(2^(b-1) - 1)) as fp16 straight into fc_out's activation operand;
-    fc_out then runs its contraction only.  This is exact for a CPTLinear consumer: its LoRA branch reads FQ(x)
+    writes fc_out's activation operand itself -- the INPUT LEVELS clamp(round(h / s_in[n]), +-(2^(b-1) - 1)) as fp16 for a
+    symmetric min-max input quantizer of at most 12 bits, the two fp16 limbs of FQ(h) * 2^G for any other (part2's default is
+    log, config_cpt.py:13-18) -- and fc_out then runs its contraction only.  This is exact for a CPTLinear consumer: its LoRA branch reads FQ(x)
     (cpt_model.py:112) and is folded into the weight, so nothing downstream needs h itself (part1's branch reads the raw
     activation, lora.py:149, which is why SPMLP keeps the fp32 store).  Taken in no-grad forwards when both layers quantize
-    at a calibrated width, fc_out's input quantizer is symmetric min-max of at most 12 bits and 4 n_embd is a multiple of 64;
-    anything else runs the two layers one after the other (same result: the levels are the same numbers either way)."""
+    at a calibrated width and 4 n_embd is a multiple of 64; anything else runs the two layers one after the other (same
+    result: the operand is the same numbers either way)."""
     bits = fc_in.current_bits
     qi2 = fc_out.quantizer_input
     ok = (fuse and not torch.is_grad_enabled() and x.is_cuda and x.numel() > 0 and _chain_ready(fc_in, bits) and _chain_ready(fc_out, bits)
-          and qi2.quantizer_type == 'minmax' and qi2.symmetric and 2 <= bits <= 12 and fc_in.out_features % 64 == 0
+          and qi2.quantizer_type in _lib.QTYPE_CODE_CPT and fc_in.out_features % 64 == 0
           and fc_in.out_features == fc_out.in_features and _MFMA16 and os.environ.get("SPQ_GEMM_T128", "1") != "0"
-          and _QuantGemm.path_for(fc_in.quantizer_input, fc_in.out_features, True) != _lib.PATH_F32)
+          and _QuantGemm.path_for(fc_in.quantizer_input, fc_in.out_features, True) != _lib.PATH_F32
+          and _QuantGemm.path_for(qi2, fc_out.out_features, True) != _lib.PATH_F32)
     if not ok:
         return fc_out(F.gelu(fc_in(x)))
     _lib.check_device(x.device)
@@ -455,7 +466,7 @@ def cpt_mlp_forward(fc_in, fc_out, x, fuse=True):
     x2 = x.detach().contiguous().float().view(-1, fc_in.in_features)
     M, H = x2.shape[0], fc_in.out_features
     # fc_out's activation operand: a buffer of its own (the shared workspace holds fc_in's operands while fc_in runs)
-    need = lib.spq_fwd_workspace_bytes(M, H, fc_out.out_features, 0, _lib.PATH_F16X2)
+    need = lib.spq_fwd_workspace_bytes(M, H, fc_out.out_features, 0, _QuantGemm.path_for(qi2, fc_out.out_features, True))
     buf = getattr(fc_out, "_levels_in", None)
     if buf is None or buf.numel() < need or buf.device != dev:
         buf = torch.empty(need, dtype=torch.uint8, device=dev)

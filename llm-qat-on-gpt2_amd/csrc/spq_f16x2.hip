@@ -1392,6 +1392,8 @@ struct GemmF16Args {
   int a_limbs;
   // levels-out store (spq_fwd_args::out_levels; gemm_f16x2_t128_kernel<.., LV = 1> only): y may be null then
   _Float16* lv; const float* lv_scale; int lv_ld, lv_pc; float lv_qhi;
+  // LV = 2: two fp16 limbs of FQ(v) * 2^G for any consumer quantizer (hi -> lv, lo -> lv_lo)
+  _Float16* lv_lo; const float* lv_zero; const float* lv_xscale; int lv_qtype, lv_sym, lv_bits;
 };
 
 // ---- LDS: two 64-deep stage buffers (A 256x64 f16 = 32 KB, B hi/lo 128x64 f16 = 16 KB each) + a dedicated
@@ -2132,16 +2134,22 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
     }
     // epilogue operands: fetched here, not at the tile's start (16 registers that three waves per SIMD do not leave through
     // the stage loop); the CU's other workgroups cover the load's latency
-    float4 ep_rs[2], ep_bv[2], ep_ls[2];
+    float4 ep_rs[2], ep_bv[2], ep_ls[2], ep_lz[2];
+    const float lv_pscale = (LV == 2) ? g.lv_xscale[0] : 1.f;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
       const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
       ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
       if (LV) {
         ep_ls[tn] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (LV == 2) ep_lz[tn] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < g.N) {
           if (g.lv_pc) ep_ls[tn] = *reinterpret_cast<const float4*>(g.lv_scale + n);
           else { const float s1 = g.lv_scale[0]; ep_ls[tn] = make_float4(s1, s1, s1, s1); }
+          if (LV == 2) {
+            if (g.lv_pc) ep_lz[tn] = *reinterpret_cast<const float4*>(g.lv_zero + n);
+            else { const float z1 = g.lv_zero[0]; ep_lz[tn] = make_float4(z1, z1, z1, z1); }
+          }
         }
       }
       if (n < g.N) {
@@ -2175,12 +2183,26 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
             o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
             if (EPI == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
             float* dst = g.y + (int64_t)m * g.N + n;
-            if (LV) {
+            if (LV == 1) {
               const float4 ls = ep_ls[tn];
               const float qhi = g.lv_qhi;
               if (interior || (n_ok && m < g.M))
                 store_levels4(g.lv, (int64_t)m * g.lv_ld + n, minmax_level<true>(o.x, ls.x, 0.f, -qhi, qhi), minmax_level<true>(o.y, ls.y, 0.f, -qhi, qhi),
                               minmax_level<true>(o.z, ls.z, 0.f, -qhi, qhi), minmax_level<true>(o.w, ls.w, 0.f, -qhi, qhi), 0);
+              if (!g.y) continue;
+            }
+            if (LV == 2) {                                   // the arithmetic of store_act4's limb branch
+              const float4 ls = ep_ls[tn], lz = ep_lz[tn];
+              if (interior || (n_ok && m < g.M)) {
+                const float f0 = fq_dispatch(o.x, ls.x, lz.x, g.lv_bits, g.lv_qtype, g.lv_sym) * lv_pscale;
+                const float f1 = fq_dispatch(o.y, ls.y, lz.y, g.lv_bits, g.lv_qtype, g.lv_sym) * lv_pscale;
+                const float f2 = fq_dispatch(o.z, ls.z, lz.z, g.lv_bits, g.lv_qtype, g.lv_sym) * lv_pscale;
+                const float f3 = fq_dispatch(o.w, ls.w, lz.w, g.lv_bits, g.lv_qtype, g.lv_sym) * lv_pscale;
+                union { _Float16 h[4]; uint2 u; } hi, lo;
+                split2(f0, hi.h[0], lo.h[0]); split2(f1, hi.h[1], lo.h[1]); split2(f2, hi.h[2], lo.h[2]); split2(f3, hi.h[3], lo.h[3]);
+                *reinterpret_cast<uint2*>(g.lv + (int64_t)m * g.lv_ld + n) = hi.u;
+                *reinterpret_cast<uint2*>(g.lv_lo + (int64_t)m * g.lv_ld + n) = lo.u;
+              }
               if (!g.y) continue;
             }
             if (T128_DIAG & 4) { if (o.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }   // (non-temporal stores: no change, 79.3 vs 79.2 us)
@@ -2884,14 +2906,22 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   g.xl = x.xl; g.xscale = a->x_limb_scale; g.a_limbs = x3 ? 2 : 1;
   g.lv = (_Float16*)a->out_levels; g.lv_scale = a->out_scale; g.lv_ld = (int)a->out_levels_ld; g.lv_pc = a->out_scale_per_channel;
   g.lv_qhi = 0.f;
+  g.lv_lo = (_Float16*)a->out_levels_lo; g.lv_zero = a->out_zero; g.lv_xscale = a->out_limb_scale;
+  g.lv_qtype = a->out_qtype; g.lv_sym = a->out_symmetric; g.lv_bits = a->out_bits;
   if (a->out_levels) {
-    if (!(a->out_scale && a->out_bits >= 2 && a->out_bits <= 12 && (a->N % 64) == 0 && a->out_levels_ld >= a->N && (a->out_levels_ld % 4) == 0 &&
-          aligned16(a->out_levels) && aligned16(a->out_scale))) {
-      set_error("spq_linear_lora_fwd: levels-out store needs out_scale, 2..12 out_bits, N %% 64 == 0 and a 16-B aligned level matrix with "
-                "row pitch >= N (got bits=%d N=%lld ld=%lld)", a->out_bits, (long long)a->N, (long long)a->out_levels_ld);
+    const bool limbs_out = a->out_levels_lo != nullptr;
+    const bool common = a->out_scale && (a->N % 64) == 0 && a->out_levels_ld >= a->N && (a->out_levels_ld % 4) == 0 && aligned16(a->out_levels) &&
+                        aligned16(a->out_scale);
+    const bool ok = limbs_out ? (common && a->out_zero && a->out_limb_scale && a->out_bits >= 1 && a->out_bits <= 24 && aligned16(a->out_levels_lo) &&
+                                 aligned16(a->out_zero) && (a->out_qtype == SPQ_MINMAX || a->out_qtype == SPQ_LOG || a->out_qtype == SPQ_LOG_DIRECT))
+                              : (common && a->out_bits >= 2 && a->out_bits <= 12);
+    if (!ok) {
+      set_error("spq_linear_lora_fwd: levels-out store needs out_scale, N %% 64 == 0, a 16-B aligned level matrix with row pitch >= N, and 2..12 "
+                "out_bits (levels) or out_zero + out_limb_scale + 1..24 out_bits (limbs) (got bits=%d N=%lld ld=%lld limbs=%d)", a->out_bits,
+                (long long)a->N, (long long)a->out_levels_ld, (int)limbs_out);
       return SPQ_ERR_UNSUPPORTED;
     }
-    g.lv_qhi = (float)((1 << (a->out_bits - 1)) - 1);
+    if (!limbs_out) g.lv_qhi = (float)((1 << (a->out_bits - 1)) - 1);
   }
   if (AttrOnce once(3); once.first) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_f16x2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2909,6 +2939,10 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
   }
   if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
   // default: the 16x16x32 variant (measured 85 us vs 90 us for the 32x32x16 one on the headline shape, same cycles per
@@ -2935,7 +2969,13 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     const int ntiles = 2 * g.tiles_m * g.tiles_n;
     const unsigned cus2 = T128_WGS * gemm_grid(1 << 30);
     const unsigned grid128 = (unsigned)ntiles < cus2 ? (unsigned)ntiles : cus2;
-    if (g.lv) {
+    if (g.lv && g.lv_lo) {
+      if (x3 && gelu) gemm_f16x2_t128_kernel<2, 1, 2><<<grid128, 256, T128_LDS, st>>>(g);
+      else if (x3) gemm_f16x2_t128_kernel<2, 0, 2><<<grid128, 256, T128_LDS, st>>>(g);
+      else if (gelu) gemm_f16x2_t128_kernel<1, 1, 2><<<grid128, 256, T128_LDS, st>>>(g);
+      else gemm_f16x2_t128_kernel<1, 0, 2><<<grid128, 256, T128_LDS, st>>>(g);
+    }
+    else if (g.lv) {
       if (x3 && gelu) gemm_f16x2_t128_kernel<2, 1, 1><<<grid128, 256, T128_LDS, st>>>(g);
       else if (x3) gemm_f16x2_t128_kernel<2, 0, 1><<<grid128, 256, T128_LDS, st>>>(g);
       else if (gelu) gemm_f16x2_t128_kernel<1, 1, 1><<<grid128, 256, T128_LDS, st>>>(g);

@@ -47,12 +47,13 @@ for (M, K, N, r, bits, qt) in [(8192, 768, 3072, 16, 4, 'minmax'), (8192, 768, 3
 # CPTBlock's feed-forward fc_out(gelu(fc_in(x))) (cpt_model.py:196-198): two layers + stock gelu against the fused pair
 # (GELU in fc_in's store, fc_out's input levels written by that store, no fp32 activation: cpt_mlp_forward)
 import torch.nn.functional as F
-for (M, E, bits) in [(8192, 768, 4), (32768, 768, 4), (8192, 768, 8), (8192, 1024, 4)]:
+for (M, E, bits, qt) in [(8192, 768, 4, 'minmax'), (32768, 768, 4, 'minmax'), (8192, 768, 8, 'minmax'), (8192, 1024, 4, 'minmax'),
+                         (8192, 768, 6, 'log'), (32768, 768, 6, 'log'), (8192, 768, 4, 'log')]:
     H, r = 4 * E, 16
     layers = []
     for (K, N) in ((E, H), (H, E)):
         W, bias, A, B, x0, x1 = C.make_cpt_workload(256, K, N, r, seed=1, batch=4)
-        m = pkg.CPTLinear(K, N, bit_widths=[bits, 32], quantizer_per_bit={bits: 'minmax', 32: None}, shared_lora_rank=r, shared_lora_alpha=32)
+        m = pkg.CPTLinear(K, N, bit_widths=[bits, 32], quantizer_per_bit={bits: qt, 32: None}, shared_lora_rank=r, shared_lora_alpha=32)
         with torch.no_grad():
             m.linear.weight.copy_(W); m.linear.bias.copy_(bias); m.shared_lora.lora_A.copy_(A); m.shared_lora.lora_B.copy_(B)
         layers.append(m.to(dev).eval())
@@ -72,5 +73,5 @@ for (M, E, bits) in [(8192, 768, 4), (32768, 768, 4), (8192, 768, 8), (8192, 102
         for l in layers: l.cache_operands = False
         t_two_rq = timeit(lambda: fc_out(F.gelu(fc_in(x))), 30)
         t_fused_rq = timeit(lambda: pkg.cpt_mlp_forward(fc_in, fc_out, x), 30)
-    print(f'CPT feed-forward minmax{bits} {M} tokens E={E}: two layers + gelu {t_two*1e3:.4f} ms ({flop/t_two/1e12:.0f} TFLOP/s), fused pair '
+    print(f'CPT feed-forward {qt}{bits} {M} tokens E={E}: two layers + gelu {t_two*1e3:.4f} ms ({flop/t_two/1e12:.0f} TFLOP/s), fused pair '
           f'{t_fused*1e3:.4f} ms ({flop/t_fused/1e12:.0f} TFLOP/s); weights re-quantized every call: {t_two_rq*1e3:.4f} vs {t_fused_rq*1e3:.4f} ms', flush=True)
