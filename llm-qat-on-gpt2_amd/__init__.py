@@ -12,8 +12,9 @@ from .calibration import SpqComm, allreduce_calibration_stats, calibrate_layer, 
 from . import cpt, deploy, synthetic
 from .blocks import SPMLP, SPAttention, SPBlock, SPLMHeadModel, SPModel, SwitchableLayerNorm
 from .cpt import CPTLinear, LoRAAdapter, GradientQuantizer, calibrate_cpt_layer, calibrate_cpt_model, cpt_mlp_forward
+from .graphs import GraphedForward
 
 __all__ = ["SPLinearWithLoRA", "LoRALayer", "LearnableFakeQuantize", "MinMaxQuantizationFunction",
            "LogQuantizationFunction", "apply_minmax_quantization", "apply_log_quantization", "fake_quantize",
            "allreduce_calibration_stats", "calibrate_layer", "calibrate_model", "SpqComm",
-           "SwitchableLayerNorm", "SPMLP", "SPAttention", "SPBlock", "SPModel", "SPLMHeadModel", "deploy", "cpt", "CPTLinear", "LoRAAdapter", "GradientQuantizer", "calibrate_cpt_layer", "calibrate_cpt_model", "cpt_mlp_forward"]
+           "SwitchableLayerNorm", "SPMLP", "SPAttention", "SPBlock", "SPModel", "SPLMHeadModel", "deploy", "cpt", "CPTLinear", "LoRAAdapter", "GradientQuantizer", "calibrate_cpt_layer", "calibrate_cpt_model", "cpt_mlp_forward", "GraphedForward"]
