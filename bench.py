@@ -68,13 +68,19 @@ def launch_ranks(n, argv, script=None):
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
     worst = 0
     try:
-        for p in procs:
-            rc = p.wait()
-            if rc != 0 and worst == 0:
-                worst = rc
-                for q in procs:                      # one rank died: the others would wait in a collective forever
-                    if q.poll() is None:
+        live = list(procs)
+        while live:                                  # poll ALL ranks: a rank that dies while an earlier one sits in a collective
+            for p in list(live):                     # must be noticed at once, not after that collective's time-out
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0 and worst == 0:
+                    worst = rc
+                    for q in live:                   # one rank died: the others would wait in a collective forever
                         q.terminate()
+            if live:
+                time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
