@@ -1936,6 +1936,9 @@ constexpr int T128_STAGE = T128_STAGE_A + 2 * STAGE_B;     // 48 KB
 #endif
 constexpr bool T128_DEFER = T128_WGS == 3;
 constexpr int T128_LDS = T128_DEFER ? T128_STAGE : T128_STAGE + 4 * EPI_WAVE;
+#ifndef T128_REUSE_BHI
+#define T128_REUSE_BHI 1
+#endif
 #ifndef T128_GROUP_M
 #define T128_GROUP_M 8      // measured at the headline shape: 8 -> 81.5 us, 16 -> 82.9, 32 -> 84.5, 4 -> 84.5
 #endif
@@ -1990,11 +1993,15 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
     const _Float16* Ab = A + (int64_t)tbm * lda + k0;
     const _Float16* Bhb = Bh + (int64_t)tbn * ldb + k0;
     const _Float16* Blb = Bl + (int64_t)tbn * ldb + k0;
+    // a one-limb stage (tlo x Bhi, lo x Whi) always follows the two-limb stage of the SAME k block in the same tile, whose B-hi
+    // copy is still in the buffer (nothing overwrites that region in between): only its A operand is copied -- 16 KB instead
+    // of 32 KB, a fifth of the copy bytes of a three-product tile
+    const bool copy_bh = two || !T128_REUSE_BHI || (T128_DIAG & 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       glds16(Ab + (pc_row[i] * lda + pc_col[i]), smem + (4 * w + i) * 1024);
       const int off = pc_row[i] * ldb + pc_col[i];
-      glds16(Bhb + off, smem + T128_STAGE_A + (4 * w + i) * 1024);
+      if (copy_bh) glds16(Bhb + off, smem + T128_STAGE_A + (4 * w + i) * 1024);
       if (two) glds16(Blb + off, smem + T128_STAGE_A + STAGE_B + (4 * w + i) * 1024);
     }
   };
