@@ -120,3 +120,28 @@ def test_levels_out_rejected_where_unsupported(pkg):
     q = fc_out.quantizer_input
     with pytest.raises(pkg._lib.SpqError):
         fc_in._gemm.run(x2, fc_in.linear.bias, fc_in.quantizer_input, True, levels_out=(buf, 500, q))   # row pitch < N
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_cpt_mlp_random_shapes_match_the_two_launch_chain(pkg, seed):
+    """random hidden sizes (multiples of 64), token counts (ragged against the 128 / 256-row tiles), widths and quantizer types:
+    the fused pair is the two-launch chain on the same activation, bit for bit"""
+    g = torch.Generator().manual_seed(9000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    E = 8 * ri(4, 40)
+    H = 64 * ri(1, 12)
+    M = 4 * ri(1, 300)
+    qtype = "minmax" if seed % 2 == 0 else "log"
+    bits = ri(2, 12) if qtype == "minmax" else ri(2, 8)
+    fc_in, fc_out, _, _, x = make_chain(pkg, E, H, bits, qtype, M, seed=seed, rank=ri(1, 32))
+    xd = x.to(DEV)
+    with torch.no_grad():
+        y_fused = pkg.cpt_mlp_forward(fc_in, fc_out, xd)
+        h = fc_in._gemm.run(xd.view(-1, E), fc_in.linear.bias, fc_in.quantizer_input, True, epilogue=pkg._lib.EPILOGUE_GELU)
+        y_chain = fc_out(h.view(*xd.shape[:-1], H))
+        y_plain = fc_out(F.gelu(fc_in(xd)))
+    assert fc_out._last_path in (pkg._lib.PATH_F16X2, pkg._lib.PATH_F16X3)
+    assert torch.equal(y_fused, y_chain), (E, H, M, bits, qtype)
+    # against the plain three calls: the same function up to level flips of single elements of h
+    close = ((y_fused - y_plain).abs() <= 1e-5 * y_plain.abs() + 1e-5 * y_plain.pow(2).mean().sqrt()).all(dim=-1).float().mean().item()
+    assert close >= 0.97, (close, E, H, M, bits, qtype)
