@@ -1079,14 +1079,13 @@ __device__ unsigned long long g_xp_stamps[2048 * 8 * 4];
 #define SPQ_XP_STAMP(var) const unsigned long long var = 0
 #endif
 template <int ROWS, int A8, bool LN>   // A8 0: fp16 levels; 1: bytes q + 128; 2: int8 q
-__global__ __launch_bounds__(ROWS * 16, 2) void xpass_stream_kernel(XPassArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char xsm[];
+__device__ __forceinline__ void xpass_stream_body(const XPassArgs& a, char* xsm, const int block) {
   constexpr int NW = ROWS / 4, SLOT = xs_slot(ROWS), XS_X = ROWS * 256, APW = 16 / NW;   // waves; FQ(A)^T pieces per wave
   float* lnst = reinterpret_cast<float*>(xsm + 3 * SLOT);   // LN only: {mean, den} per row
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ws = w & 3, rg = w >> 2;                        // k-slice of a chunk; 16-row group
-  const int m0 = blockIdx.x * ROWS;
+  const int m0 = block * ROWS;
   const float qhi = (float)((1 << (a.bits - 1)) - 1), qlo = -qhi;
   const int l15 = lane & 15, q4 = lane >> 4;
   const int nck = (SPQ_XP_DIAG & 32) ? 2 : a.K / 64;
@@ -1196,14 +1195,46 @@ __global__ __launch_bounds__(ROWS * 16, 2) void xpass_stream_kernel(XPassArgs a)
     }
   }
 #if SPQ_XP_DIAG & 128
-  if (lane == 0 && blockIdx.x < 2048) {
-    unsigned long long* o = g_xp_stamps + ((int64_t)blockIdx.x * 8 + w) * 4;
+  if (lane == 0 && block < 2048) {
+    unsigned long long* o = g_xp_stamps + ((int64_t)block * 8 + w) * 4;
     o[0] = st_wait; o[1] = st_bar; o[2] = st_body; o[3] = __builtin_readcyclecounter() - t_begin;
   }
 #endif
   __syncthreads();                                          // the ring is free for the reduction
   if ((SPQ_XP_DIAG & 16) && a.M != 12345) return;
   xpass16_finish<ROWS>(a, acc, reinterpret_cast<float*>(xsm), m0, tid);
+}
+
+template <int ROWS, int A8, bool LN>
+__global__ __launch_bounds__(ROWS * 16, 2) void xpass_stream_kernel(XPassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char xsm[];
+  xpass_stream_body<ROWS, A8, LN>(a, xsm, (int)blockIdx.x);
+}
+
+// The same launch with the weight-side row work as EXTRA workgroups (spq_fwd_args.prepare): blocks 0 .. nx-1 are the activation
+// pass, every later block prepares ROWS / 4 weight rows, one wave per row (prep_row_wave: FQ(W), fold sx, FQ(B) column, exponent,
+// limb split).  The two are independent once FQ(A)^T exists (fq_transpose_kernel, a few dozen workgroups, goes first), both are
+// latency-bound streams, and at the shapes where 32-row activation workgroups cover the chip once a CU has room for a second
+// workgroup of this size: the row blocks run beside the activation blocks instead of as a launch of their own before them.
+// MODE as prep_wave_kernel (0: fp16 limb planes, 1: int8 levels).
+template <int ROWS, int A8, int MODE>
+__global__ __launch_bounds__(ROWS * 16, 2) void xpass_stream_prep_kernel(XPassArgs a, PrepArgs pa, int nx) {
+  extern __shared__ __attribute__((aligned(16))) char xsm[];
+  if ((int)blockIdx.x < nx) { xpass_stream_body<ROWS, A8, false>(a, xsm, (int)blockIdx.x); return; }
+  constexpr int NW = ROWS / 4;                              // waves = rows per block
+  const int n0 = ((int)blockIdx.x - nx) * NW;
+  float (*sB)[128] = reinterpret_cast<float (*)[128]>(xsm);   // the rows' raw LoRA-B columns B[j][n0 .. n0 + NW - 1], as prep_wave_kernel
+  const bool staged = pa.B && n0 + NW - 1 < pa.N;
+  float* d0 = nullptr; float* d1 = nullptr;
+  float v0 = 0.f, v1 = 0.f;
+  if (staged) {
+    const int e0 = threadIdx.x, e1 = threadIdx.x + NW * 64;
+    d0 = &sB[e0 % NW][e0 / NW];
+    if (e0 < pa.r * NW) v0 = pa.B[(int64_t)(e0 / NW) * pa.N + n0 + (e0 % NW)];
+    if (e1 < pa.r * NW) { d1 = &sB[e1 % NW][e1 / NW]; v1 = pa.B[(int64_t)(e1 / NW) * pa.N + n0 + (e1 % NW)]; }
+  }
+  const int wv = threadIdx.x >> 6;
+  prep_row_wave<MODE, 4>(pa, n0 + wv, threadIdx.x & 63, staged ? &sB[wv][0] : nullptr, d0, d1, v0, v1);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -2763,18 +2794,26 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   const bool panel_ok = (a->K % 64 == 0) && L.Rp <= 64 && aligned16(a->x) && (a->r == 0 || aligned16(a->a_prep)) && aligned16(x.sx) &&
                         aligned16(x.zx);
   const bool do_xpass = a->stage != SPQ_STAGE_CONTRACTION, do_gemm = a->stage != SPQ_STAGE_ACTIVATIONS;
-  // a->prepare: the weight-side operands are (re)made by this call.  When the 16-row activation kernel runs and every one of
-  // its workgroups gets at most 8 weight rows, the row work rides inside that kernel (FQ(A)^T, which the pass itself consumes,
-  // goes first as a launch of a few dozen workgroups); otherwise the ordinary preparation launch is issued first.
+  // a->prepare: the weight-side operands are (re)made by this call.  Where the streaming activation kernel runs, the row work
+  // goes into ITS launch as extra workgroups (xpass_stream_prep_kernel; FQ(A)^T, which the pass itself consumes, goes first as a
+  // launch of a few dozen workgroups; SPQ_PREP_ROLE=0 turns that off); otherwise the ordinary preparation launch is issued first
+  // (SPQ_PREP_INPASS=1: the earlier variant that spreads the rows over the 16-row activation kernel's own workgroups).
   PrepArgs pa;
   int prep_rows = 0, at_blocks = 0;
-  static int rows16 = -1, fuse_prep = -1;
+  static int rows16 = -1;
   if (rows16 < 0) {
     const char* e = getenv("SPQ_XPASS_ROWS16");
     rows16 = (e && e[0] == '0') ? 0 : 1;
-    fuse_prep = 1;      // a->prepare asks for it; the host side decides (sp_linear.py: fuse_prepare)
   }
+  const char* ip = getenv("SPQ_PREP_INPASS");               // 1: the earlier in-pass variant (row work spread over the 16-row
+  const int fuse_prep = (ip && ip[0] == '1') ? 1 : 0;       // activation kernel's workgroups; measured slower, kept for the A/B)
   const bool use_rows16 = panel_ok && !(x.ascale && a->r > 0) && rows16 && xgrid < 2 * gemm_grid(1 << 30);
+  const char* xs_env = getenv("SPQ_XPASS_STREAM");        // 0: the panel kernels, 1 / unset: auto, 16 / 32: forced row count (tuning, tests)
+  const int stream16 = xs_env ? atoi(xs_env) : 1;
+  const bool stream_ok = panel_ok && stream16 && a->r > 0 && !x.limbs && !x.lora_fq && !x.ascale;
+  const char* re = getenv("SPQ_PREP_ROLE");                // read per call (tests flip it)
+  const int role_env = (re && re[0] == '0') ? 0 : 1;
+  bool role_prep = false;                                  // the row work as extra workgroups of the streaming activation launch
   if (a->prepare && do_xpass) {
     bool wave_ok = false;
     int prc = prepare_fill(a->prepare, pa, at_blocks, wave_ok);
@@ -2782,7 +2821,14 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     if (a->prepare->N != a->N || a->prepare->K != a->K || a->prepare->r < a->r) { set_error("spq_linear_lora_fwd: prepare args describe another layer"); return SPQ_ERR_INVALID; }
     const int64_t xb = (a->M + XR16 - 1) / XR16;
     const int64_t rows_each = (pad_to(a->N, GN) + xb - 1) / xb;
-    if (fuse_prep && use_rows16 && wave_ok && rows_each <= 8 && a->K <= 1024) {   // the in-pass row code covers K <= 1024
+    if (role_env && stream_ok && !a->ln_weight && wave_ok && a->K <= 1024) {
+      role_prep = true;
+      if (at_blocks) {
+        fq_transpose_kernel<<<(unsigned)at_blocks, 256, 0, st>>>(pa);
+        prc = check_launch("spq_linear_lora_fwd(FQ(A)^T)");
+        if (prc) return prc;
+      }
+    } else if (fuse_prep && use_rows16 && wave_ok && rows_each <= 8 && a->K <= 1024) {   // the in-pass row code covers K <= 1024
       prep_rows = (int)rows_each;
       if (at_blocks) {
         fq_transpose_kernel<<<(unsigned)at_blocks, 256, 0, st>>>(pa);
@@ -2816,9 +2862,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)xpass_rows16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, XP16R_LDS);
       (void)hipFuncSetAttribute((const void*)xpass_rows16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, XP16R_LDS);
     }
-    const char* xs_env = getenv("SPQ_XPASS_STREAM");        // 0: the panel kernels, 1 / unset: auto, 16 / 32: forced row count (tuning, tests)
-    const int stream16 = xs_env ? atoi(xs_env) : 1;
-    const bool use_stream = stream16 && a->r > 0 && !x.limbs && !x.lora_fq && !x.ascale && prep_rows == 0;
+    const bool use_stream = stream_ok && prep_rows == 0;
     if (use_stream) {
       if (AttrOnce once(7); once.first) {
 #define SPQ_XS_ATTR(R, A8, LN) (void)hipFuncSetAttribute((const void*)xpass_stream_kernel<R, A8, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, xs_lds(R))
@@ -2831,6 +2875,20 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
       // 32-row workgroups halve the FQ(A)^T traffic through L2; taken once they still cover every CU
       const bool r32 = stream16 == 32 || (stream16 != 16 && (a->M + 31) / 32 >= gemm_grid(1 << 30));
       const bool ln = x.ln_w != nullptr;
+      if (role_prep) {
+        if (AttrOnce once(8); once.first) {
+#define SPQ_XSP_ATTR(R, A8, MODE) (void)hipFuncSetAttribute((const void*)xpass_stream_prep_kernel<R, A8, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, xs_lds(R))
+          SPQ_XSP_ATTR(16, 0, 0); SPQ_XSP_ATTR(16, 1, 0); SPQ_XSP_ATTR(16, 2, 1); SPQ_XSP_ATTR(32, 0, 0); SPQ_XSP_ATTR(32, 1, 0); SPQ_XSP_ATTR(32, 2, 1);
+#undef SPQ_XSP_ATTR
+        }
+        const int R = r32 ? 32 : 16;
+        const unsigned nx = (unsigned)((a->M + R - 1) / R);
+        const unsigned nrow = (unsigned)((pad_to(a->N, GN) + R / 4 - 1) / (R / 4));
+#define SPQ_XSP_LAUNCH(R, A8, MODE) xpass_stream_prep_kernel<R, A8, MODE><<<nx + nrow, R * 16, xs_lds(R), st>>>(x, pa, (int)nx)
+        if (r32) { if (x.a8 == 0) SPQ_XSP_LAUNCH(32, 0, 0); else if (x.a8 == 1) SPQ_XSP_LAUNCH(32, 1, 0); else SPQ_XSP_LAUNCH(32, 2, 1); }
+        else { if (x.a8 == 0) SPQ_XSP_LAUNCH(16, 0, 0); else if (x.a8 == 1) SPQ_XSP_LAUNCH(16, 1, 0); else SPQ_XSP_LAUNCH(16, 2, 1); }
+#undef SPQ_XSP_LAUNCH
+      } else
 #define SPQ_XS_LAUNCH(R, A8, LN) xpass_stream_kernel<R, A8, LN><<<(unsigned)((a->M + R - 1) / R), R * 16, xs_lds(R), st>>>(x)
 #define SPQ_XS_PICK(R) do { if (ln) { if (x.a8 == 0) SPQ_XS_LAUNCH(R, 0, true); else if (x.a8 == 1) SPQ_XS_LAUNCH(R, 1, true); else SPQ_XS_LAUNCH(R, 2, true); } \
                             else { if (x.a8 == 0) SPQ_XS_LAUNCH(R, 0, false); else if (x.a8 == 1) SPQ_XS_LAUNCH(R, 1, false); else SPQ_XS_LAUNCH(R, 2, false); } } while (0)

@@ -214,11 +214,12 @@ class SPLinearWithLoRA(nn.Module):
         self.backward_limbs = True                # d/dx on the f16 MFMA limb kernel (False: fp32 MFMA kernel)
         # weight-side limb split on a side stream, under the activation pass (opt-in: measured slower)
         self.overlap_prepare = os.environ.get('SPQ_OVERLAP_PREPARE', '0') == '1'
-        # True: a re-quantising forward (training mode, or cache_operands off) makes the weight-side operands inside its
-        # activation pass (spq_fwd_args.prepare) instead of launching their preparation.  Off by default: measured 3-4 us
-        # SLOWER per forward at the headline shape (the extra FQ(A)^T launch and the fatter activation kernel cost more than
-        # the preparation launch they replace); SPQ_FUSE_PREPARE=1 turns it on
-        self.fuse_prepare = os.environ.get('SPQ_FUSE_PREPARE', '0') == '1'
+        # True (default): a re-quantising forward (training mode, or cache_operands off) hands the weight-side preparation to the
+        # forward call (spq_fwd_args.prepare).  Where the streaming activation kernel runs, the row work then rides in the SAME
+        # launch as extra workgroups beside the activation workgroups (xpass_stream_prep_kernel; FQ(A)^T, which the pass
+        # consumes, goes first as a launch of a few dozen workgroups): 0.0955 -> 0.092 ms per forward at the headline shape.
+        # Elsewhere the library issues the ordinary preparation launch itself.  SPQ_FUSE_PREPARE=0: prepare from Python, as before
+        self.fuse_prepare = os.environ.get('SPQ_FUSE_PREPARE', '1') != '0'
         self._bwd_gemm = None
         self._wq_t = None                         # (signature, FQ(W)^T) for the backward, see _fq_weight_t
         self._last_t = None                       # LoRA-down product of the last training forward (consumed by autograd)

@@ -47,8 +47,28 @@ CASES = [
 ]
 
 
+# how the library serves spq_fwd_args.prepare: "role" (default) = extra workgroups of the streaming activation launch where that
+# kernel runs; "inpass" = the earlier variant, rows spread over the 16-row activation kernel's own workgroups; "launch" = always
+# the ordinary preparation launch, issued by the library
+MODES = {"role": {}, "inpass": {"SPQ_PREP_ROLE": "0", "SPQ_PREP_INPASS": "1"}, "launch": {"SPQ_PREP_ROLE": "0"}}
+
+
+@pytest.fixture(params=list(MODES))
+def prep_mode(request):
+    import os
+    old = {k: os.environ.get(k) for k in ("SPQ_PREP_ROLE", "SPQ_PREP_INPASS")}
+    for k in old:
+        os.environ.pop(k, None)
+    os.environ.update(MODES[request.param])
+    yield request.param
+    for k, v in old.items():
+        os.environ.pop(k, None)
+        if v is not None:
+            os.environ[k] = v
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c))
-def test_fused_prepare_is_bit_identical(pkg, case):
+def test_fused_prepare_is_bit_identical(pkg, case, prep_mode):
     M, K, N, r, bits, qtype = case[:6]
     layer, x = build(pkg, M, K, N, r, bits, qtype, per_channel=case[6] if len(case) > 6 else True)
     with torch.no_grad():
