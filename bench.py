@@ -292,6 +292,10 @@ def main():
         # packets on the launch stream; on every step that alone took 8 % off the throughput it was meant to explain); EVERY
         # is chosen so that even a 20-step run averages over >= 8 launches
         EVERY = int(os.environ.get('SPQ_BENCH_EVENT_EVERY', '8'))
+        if args.steps < 64 and 'SPQ_BENCH_EVENT_EVERY' not in os.environ:
+            # a short region (the driver's 20 steps): ONE event pair inside it -- each pair is two marker packets on the launch
+            # stream, ~20 us of a 2 ms region apiece -- and the other >= 7 samples on the first repeat region below
+            EVERY = max(EVERY, args.steps)
         n_main = (args.steps + EVERY - 1) // EVERY
         n_extra = max(0, 8 - n_main)      # a short run: further samples ride on the first repeat region below, >= 8 launches in all
         ev = HipEvents(n_main + n_extra)
