@@ -111,10 +111,17 @@ __device__ __forceinline__ float log_level(float x, float log_min, float log_ran
   const float eps = 1e-5f;
   const float mag = fmaxf(fabsf(x), eps);                          // :45
   const float lg_fast = __builtin_amdgcn_logf(mag);                // :47, approximately
-  float pre = log_pre_round<SYM>(lg_fast, log_min, log_range, p);
-  // |lg_fast - lg| <= 2 ulp, propagated through the slope of pre(lg), plus the roundings of the chain itself
-  const float slope = (SYM ? 2.0f : 1.0f) * p.n2 / fmaxf(log_range, eps);
-  const float err = 2.4e-7f * fmaxf(fabsf(lg_fast), 1.f) * slope + 1e-6f * fmaxf(fabsf(pre), 1.f);
+  // fast pre-round value: the division of :49 as a multiplication by v_rcp_f32(range) (the two IEEE divisions per element --
+  // this one and the one in the error bound's slope -- were a fifth of the log fake-quant's instructions); only rint(pre)
+  // is used, and the tie test below sends every element whose rounding could differ through the exact chain
+  const float rr = __builtin_amdgcn_rcpf(fmaxf(log_range, eps));
+  const float k2 = (SYM ? 2.0f : 1.0f) * p.n2;
+  const float lnf = clampf((lg_fast - log_min) * rr, 0.f, 1.f);
+  float pre = SYM ? ((lnf - 0.5f) * 2.0f) * p.n2 : lnf * p.n2;
+  // |lg_fast - lg| <= 2 ulp, propagated through the slope of pre(lg); (lg - min) * rr against (lg - min) / range: <= 2.5 ulp of a
+  // value that the clamp keeps within [0, 1]; plus the roundings of the chain itself
+  const float slope = k2 * rr;
+  const float err = 2.4e-7f * fmaxf(fabsf(lg_fast), 1.f) * slope + 3.0e-7f * k2 + 1e-6f * fmaxf(fabsf(pre), 1.f);
   const float tie_dist = 0.5f - fabsf(pre - rintf(pre));
   if (!(tie_dist > err)) pre = log_pre_round<SYM>(log2_rn(mag), log_min, log_range, p);   // also catches NaN
   return (x != x) ? x : clampf(rintf(pre), p.qlo, p.qhi);          // :55-56 / :60-61 (a NaN input stays NaN, as torch.clamp keeps it)

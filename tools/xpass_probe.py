@@ -11,9 +11,10 @@ def child():
     import llm_qat_on_gpt2_amd as pkg
     from llm_qat_on_gpt2_amd import synthetic as S
     dev = "cuda:0"
-    M, K, N, r, bits = int(os.environ.get("XP_M", 8192)), int(os.environ.get("XP_K", 768)), int(os.environ.get("XP_N", 3072)), 64, 4
+    M, K, N, r, bits = int(os.environ.get("XP_M", 8192)), int(os.environ.get("XP_K", 768)), int(os.environ.get("XP_N", 3072)), 64, int(os.environ.get("XP_BITS", 4))
+    qtype = os.environ.get("XP_QTYPE", "minmax")
     W, bias, A, B, _, _ = S.make_workload(8, K, N, r, seed=0)
-    layer = pkg.SPLinearWithLoRA(K, N, [bits, 32], {bits: r, 32: 0}, {bits: 64, 32: 0}, {bits: "minmax", 32: None}, per_channel=True)
+    layer = pkg.SPLinearWithLoRA(K, N, [bits, 32], {bits: r, 32: 0}, {bits: 64, 32: 0}, {bits: qtype, 32: None}, per_channel=True)
     with torch.no_grad():
         layer.linear.weight.copy_(W); layer.linear.bias.copy_(bias)
         layer.lora_adapters[f"{bits}bit"].lora_A.copy_(A); layer.lora_adapters[f"{bits}bit"].lora_B.copy_(B)
