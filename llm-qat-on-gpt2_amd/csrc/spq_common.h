@@ -126,16 +126,24 @@ __device__ __forceinline__ float log_level(float x, float log_min, float log_ran
   if (!(tie_dist > err)) pre = log_pre_round<SYM>(log2_rn(mag), log_min, log_range, p);   // also catches NaN
   return (x != x) ? x : clampf(rintf(pre), p.qlo, p.qhi);          // :55-56 / :60-61 (a NaN input stays NaN, as torch.clamp keeps it)
 }
-// :57,:64-74 -> dequantised value
+// :57,:64,:66 -> the normalised level: a function of the integer level alone (two IEEE divisions)
 template <bool SYM>
-__device__ __forceinline__ float log_dequant(float x, float q, float log_min, float log_range,
-                                             const LogParams& p) {
+__device__ __forceinline__ float log_qn(float q, const LogParams& p) {
   float qn;
   if (SYM) {
     qn = q / p.denom + 0.5f;                                       // :57
     if (p.full > 0.f) qn = (qn * p.full) / p.full;                 // :64 (part1 only)
   }
   else     qn = q / p.denom;                                       // :66
+  return qn;
+}
+// :57,:64-74 -> dequantised value.  qn_lut (nullable): log_qn of every level qlo .. qhi, tabulated by the caller with log_qn
+// itself (so the same numbers) -- the activation kernels keep it in LDS for widths of at most 8 bits, where the two divisions
+// per ELEMENT were a third of the log fake-quant's instructions
+template <bool SYM>
+__device__ __forceinline__ float log_dequant(float x, float q, float log_min, float log_range,
+                                             const LogParams& p, const float* qn_lut = nullptr) {
+  const float qn = qn_lut ? qn_lut[(q == q) ? (int)(q - p.qlo) : 0] : log_qn<SYM>(q, p);   // (a NaN level: the sign below is NaN anyway)
   float x_hat = qn * log_range + log_min;                          // :68 (unclamped range)
   float mag = __builtin_amdgcn_exp2f(x_hat);                       // :70  v_exp_f32 (<= 1 ulp, like ATen's pow); |x_hat| < 64 here
   float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : ((x == 0.f) ? 0.f : x));   // :43 torch.sign (NaN -> NaN)

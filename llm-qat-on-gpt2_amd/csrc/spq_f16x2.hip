@@ -98,7 +98,7 @@ struct PrepArgs {
 };
 
 template <int QT, bool SYM>
-__device__ __forceinline__ float fq_value(float v, float s, float z, int bits, bool log_direct = false) {
+__device__ __forceinline__ float fq_value(float v, float s, float z, int bits, bool log_direct = false, const float* qn_lut = nullptr) {
   if (QT == SPQ_MINMAX) {
     float qlo, qhi;
     if (SYM) { qhi = (float)((1 << (bits - 1)) - 1); qlo = -qhi; }
@@ -106,15 +106,28 @@ __device__ __forceinline__ float fq_value(float v, float s, float z, int bits, b
     return minmax_dequant<SYM>(minmax_level<SYM>(v, s, z, qlo, qhi), s, z);
   } else {
     const LogParams lp = make_log_params(bits, SYM, log_direct);
-    return log_dequant<SYM>(v, log_level<SYM>(v, z, s, lp), z, s, lp);
+    return log_dequant<SYM>(v, log_level<SYM>(v, z, s, lp), z, s, lp, qn_lut);
   }
 }
 
-__device__ __forceinline__ float fq_dispatch(float v, float s, float z, int bits, int qtype, int sym) {
+__device__ __forceinline__ float fq_dispatch(float v, float s, float z, int bits, int qtype, int sym, const float* qn_lut = nullptr) {
   if (bits >= 32) return v;
   if (qtype == SPQ_MINMAX) return sym ? fq_value<SPQ_MINMAX, true>(v, s, z, bits) : fq_value<SPQ_MINMAX, false>(v, s, z, bits);
   const bool direct = qtype == SPQ_LOG_DIRECT;
-  return sym ? fq_value<SPQ_LOG, true>(v, s, z, bits, direct) : fq_value<SPQ_LOG, false>(v, s, z, bits, direct);
+  return sym ? fq_value<SPQ_LOG, true>(v, s, z, bits, direct, qn_lut) : fq_value<SPQ_LOG, false>(v, s, z, bits, direct, qn_lut);
+}
+
+// log quantizers of at most 8 bits: log_qn of every level, tabulated once per workgroup (256 floats of LDS); returns the table or
+// null.  Every thread of the workgroup must call it (barrier inside).
+__device__ __forceinline__ const float* fill_log_qn_lut(float* lut, int bits, int qtype, int sym) {
+  const bool use = qtype != SPQ_MINMAX && bits >= 1 && bits <= 8;
+  if (use) {
+    const LogParams lp = make_log_params(bits, sym != 0, qtype == SPQ_LOG_DIRECT);
+    const int n = (int)(lp.qhi - lp.qlo) + 1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lut[i] = sym ? log_qn<true>(lp.qlo + (float)i, lp) : log_qn<false>(lp.qlo + (float)i, lp);
+  }
+  __syncthreads();
+  return use ? lut : nullptr;
 }
 
 // nn.GELU() (models_sp.py:107): x * 0.5 * (1 + erf(x / sqrt(2))), the operation order of ATen's CPU kernel
@@ -545,12 +558,12 @@ __device__ __forceinline__ void xpass_finish(const XPassArgs& a, const f32x16 (&
 // activation operand of four consecutive elements at element index idx: exact integer levels (fp16, or bytes q + 128
 // when a8) for the symmetric-minmax path, or the two fp16 limbs of FQ(x) * 2^G for any other input quantizer
 __device__ __forceinline__ void store_act4(const XPassArgs& a, int64_t idx, float4 v, float4 sc, float4 zp, float qlo, float qhi,
-                                           float pscale) {
+                                           float pscale, const float* qn_lut = nullptr) {
   if (a.limbs) {
-    const float f0 = fq_dispatch(v.x, sc.x, zp.x, a.bits, a.qtype, a.symmetric) * pscale;     // * 2^G exact
-    const float f1 = fq_dispatch(v.y, sc.y, zp.y, a.bits, a.qtype, a.symmetric) * pscale;
-    const float f2 = fq_dispatch(v.z, sc.z, zp.z, a.bits, a.qtype, a.symmetric) * pscale;
-    const float f3 = fq_dispatch(v.w, sc.w, zp.w, a.bits, a.qtype, a.symmetric) * pscale;
+    const float f0 = fq_dispatch(v.x, sc.x, zp.x, a.bits, a.qtype, a.symmetric, qn_lut) * pscale;     // * 2^G exact
+    const float f1 = fq_dispatch(v.y, sc.y, zp.y, a.bits, a.qtype, a.symmetric, qn_lut) * pscale;
+    const float f2 = fq_dispatch(v.z, sc.z, zp.z, a.bits, a.qtype, a.symmetric, qn_lut) * pscale;
+    const float f3 = fq_dispatch(v.w, sc.w, zp.w, a.bits, a.qtype, a.symmetric, qn_lut) * pscale;
     union { _Float16 h[4]; uint2 u; } hi, lo;
     split2(f0, hi.h[0], lo.h[0]); split2(f1, hi.h[1], lo.h[1]); split2(f2, hi.h[2], lo.h[2]); split2(f3, hi.h[3], lo.h[3]);
     *reinterpret_cast<uint2*>(a.qx + idx) = hi.u;
@@ -572,9 +585,9 @@ __device__ __forceinline__ void store_act4(const XPassArgs& a, int64_t idx, floa
 }
 
 // FQ of four consecutive activations (the LoRA-down operand of part2's CPTLinear, cpt_model.py:112)
-__device__ __forceinline__ float4 fq_act4(const XPassArgs& a, float4 v, float4 sc, float4 zp) {
-  return make_float4(fq_dispatch(v.x, sc.x, zp.x, a.bits, a.qtype, a.symmetric), fq_dispatch(v.y, sc.y, zp.y, a.bits, a.qtype, a.symmetric),
-                     fq_dispatch(v.z, sc.z, zp.z, a.bits, a.qtype, a.symmetric), fq_dispatch(v.w, sc.w, zp.w, a.bits, a.qtype, a.symmetric));
+__device__ __forceinline__ float4 fq_act4(const XPassArgs& a, float4 v, float4 sc, float4 zp, const float* qn_lut = nullptr) {
+  return make_float4(fq_dispatch(v.x, sc.x, zp.x, a.bits, a.qtype, a.symmetric, qn_lut), fq_dispatch(v.y, sc.y, zp.y, a.bits, a.qtype, a.symmetric, qn_lut),
+                     fq_dispatch(v.z, sc.z, zp.z, a.bits, a.qtype, a.symmetric, qn_lut), fq_dispatch(v.w, sc.w, zp.w, a.bits, a.qtype, a.symmetric, qn_lut));
 }
 
 // four consecutive integer levels -> level matrix at element index idx (fp16, or bytes q + 128 when a8)
@@ -760,6 +773,8 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
   const float pscale = a.limbs ? a.xscale[0] : 1.f;
   const bool with_lora = a.r > 0;
   const int l31 = lane & 31, h = lane >> 5;
+  __shared__ float s_qn[256];
+  const float* qn_lut = (a.limbs || a.lora_fq) ? fill_log_qn_lut(s_qn, a.bits, a.qtype, a.symmetric) : nullptr;   // (uniform branch)
 
   f32x16 acc[2];
 #pragma unroll
@@ -820,7 +835,7 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
         const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + q_row * 256 + q_pos * 16);
         const float4 sc = *reinterpret_cast<const float4*>(sxs + c * 64 + q_kof);
         const float4 zp = *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + q_kof);
-        store_act4(a, q_dst + k0, v, sc, zp, qlo, qhi, pscale);
+        store_act4(a, q_dst + k0, v, sc, zp, qlo, qhi, pscale, qn_lut);
       }
       // ---- t += x . FQ(A): wave w owns k in [8w, 8w+8) of the chunk, lane half h the 4 contiguous k 8w+4h..+3
       if (with_lora) {
@@ -828,7 +843,7 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
         float4 av = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + l31 * 256 + ((pa ^ (l31 & 15)) << 4));
         if (a.lora_fq)                                     // every element is read by exactly one lane: FQ it in place
           av = fq_act4(a, av, *reinterpret_cast<const float4*>(sxs + c * 64 + 4 * pa),
-                       *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + 4 * pa));
+                       *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + 4 * pa), qn_lut);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int rb = t * 32 + l31;
@@ -928,6 +943,8 @@ __global__ __launch_bounds__(256, SPQ_XP16R_CH <= 4 ? 3 : 2) void xpass_rows16_k
   const float pscale = a.limbs ? a.xscale[0] : 1.f;
   const bool with_lora = a.r > 0;
   const int l15 = lane & 15, q4 = lane >> 4;
+  __shared__ float s_qn[256];
+  const float* qn_lut = (a.limbs || a.lora_fq) ? fill_log_qn_lut(s_qn, a.bits, a.qtype, a.symmetric) : nullptr;   // (uniform branch)
 
   f32x4 acc[4];
 #pragma unroll
@@ -1009,14 +1026,14 @@ __global__ __launch_bounds__(256, SPQ_XP16R_CH <= 4 ? 3 : 2) void xpass_rows16_k
         const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR16 * 256) + q_row * 256 + q_pos * 16);
         const float4 sc = *reinterpret_cast<const float4*>(sxs + c * 64 + q_kof);
         const float4 zp = *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + q_kof);
-        store_act4(a, q_dst + k0, v, sc, zp, qlo, qhi, pscale);
+        store_act4(a, q_dst + k0, v, sc, zp, qlo, qhi, pscale, qn_lut);
       }
       if (with_lora) {
         const int pa = 4 * w + q4;                         // 16-B source chunk of this lane: k = 16 w + 4 q4 .. + 3
         float4 av = *reinterpret_cast<const float4*>(xs + c * (XR16 * 256) + l15 * 256 + ((pa ^ l15) << 4));
         if (a.lora_fq)
           av = fq_act4(a, av, *reinterpret_cast<const float4*>(sxs + c * 64 + 4 * pa),
-                       *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + 4 * pa));
+                       *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + 4 * pa), qn_lut);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int rb = t * 16 + l15;
