@@ -1095,7 +1095,13 @@ __device__ unsigned long long g_xp_stamps[2048 * 8 * 4];
 #else
 #define SPQ_XP_STAMP(var) const unsigned long long var = 0
 #endif
-template <int ROWS, int A8, bool LN>   // A8 0: fp16 levels; 1: bytes q + 128; 2: int8 q
+// A8 = 3 (round 2, later): the LIMB form of the pass -- any other input quantizer (log, asymmetric, 13..24 bit): every thread
+// applies the quantize-dequantize to its four elements (fq_dispatch: the same function as the panel kernels, the log normalised
+// levels from an LDS table) and stores the two fp16 limbs of FQ(x) * 2^G (two 8-byte stores per chunk, hence vmcnt counts of
+// CP + 4 / 4); the chunk's zero points (log: minima) ride in the aux line that carries the LayerNorm weight otherwise, so the
+// LayerNorm prologue and the limb form exclude each other.  The panel kernels spent the log arithmetic (ALU-bound) and the
+// copies one after the other; here the ring keeps two chunks of copies in flight under it.
+template <int ROWS, int A8, bool LN>   // A8 0: fp16 levels; 1: bytes q + 128; 2: int8 q; 3: two fp16 limbs of FQ(x) * 2^G
 __device__ __forceinline__ void xpass_stream_body(const XPassArgs& a, char* xsm, const int block) {
   constexpr int NW = ROWS / 4, SLOT = xs_slot(ROWS), XS_X = ROWS * 256, APW = 16 / NW;   // waves; FQ(A)^T pieces per wave
   float* lnst = reinterpret_cast<float*>(xsm + 3 * SLOT);   // LN only: {mean, den} per row
@@ -1114,7 +1120,9 @@ __device__ __forceinline__ void xpass_stream_body(const XPassArgs& a, char* xsm,
   const int64_t a_step = (int64_t)4 * NW * a.K;
   // the chunk's constants: wave 0 brings the 64 scales, wave 1 / 2 the LayerNorm weight / bias, the others a dummy line
   const int auxw = ws < 3 && rg == 0 ? ws : 3;
-  const float* aux_src = (auxw == 0 && a.x_pc) ? a.sx + lane : (LN && auxw == 1) ? a.ln_w + lane : (LN && auxw == 2) ? a.ln_b + lane : nullptr;
+  static_assert(!(LN && A8 == 3), "the limb form has no LayerNorm prologue");
+  const float* aux_src = (auxw == 0 && a.x_pc) ? a.sx + lane : (LN && auxw == 1) ? a.ln_w + lane : (LN && auxw == 2) ? a.ln_b + lane
+                         : (A8 == 3 && auxw == 1 && a.x_pc) ? a.zx + lane : nullptr;
   auto issue = [&](int c, int slot) {
     char* s = xsm + slot * SLOT;
     if (!(SPQ_XP_DIAG & 8) || c < 2) glds16(x_src + c * 64, s + w * 1024); else glds4(x_src, s + XS_X + XS_A + 768);
@@ -1129,6 +1137,10 @@ __device__ __forceinline__ void xpass_stream_body(const XPassArgs& a, char* xsm,
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
   const float s_pt = a.x_pc ? 0.f : a.sx[0];
+  const float z_pt = (A8 == 3 && !a.x_pc) ? a.zx[0] : 0.f;
+  const float pscale = (A8 == 3) ? a.xscale[0] : 1.f;
+  __shared__ float s_qn[A8 == 3 ? 256 : 1];
+  const float* qn_lut = (A8 == 3) ? fill_log_qn_lut(s_qn, a.bits, a.qtype, a.symmetric) : nullptr;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the scalar's load is out of the count
   issue(0, 0);
   if (nck > 1) issue(1, 1);
@@ -1141,11 +1153,13 @@ __device__ __forceinline__ void xpass_stream_body(const XPassArgs& a, char* xsm,
   for (int c = 0; c < nck; ++c) {
     SPQ_XP_STAMP(t0);
     // chunk c's copies are done once only the younger operations remain: {store c-2, CP copies of c+1, store c-1}
+    // (A8 == 3: two limb stores per chunk instead of one level store -> CP + 4 and 4)
     if (c + 1 < nck && c >= 2) {
-      if (APW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if (A8 == 3) { if (APW == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+      else if (APW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else if (c + 1 < nck) {
       if (APW == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else if (c >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else if (c >= 2) { if (A8 == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     SPQ_XP_STAMP(t1);
@@ -1180,6 +1194,21 @@ __device__ __forceinline__ void xpass_stream_body(const XPassArgs& a, char* xsm,
     if (!LN) v = xs_ld16(xs + prow * 256 + l15 * 16);
     f32x4 sc = xs_ld16(aux + kof * 4);
     if (!a.x_pc) { sc.x = s_pt; sc.y = s_pt; sc.z = s_pt; sc.w = s_pt; }
+    if (A8 == 3) {                                          // limb form: MFMAs on the raw x, FQ + limb split of my four elements
+      f32x4 zp = xs_ld16(aux + 256 + kof * 4);
+      if (!a.x_pc) { zp.x = z_pt; zp.y = z_pt; zp.z = z_pt; zp.w = z_pt; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[t][e], acc[t], 0, 0, 0);
+      union { _Float16 h[4]; uint2 u; } hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split2(fq_dispatch(v[e], sc[e], zp[e], a.bits, a.qtype, a.symmetric, qn_lut) * pscale, hi.h[e], lo.h[e]);
+      *reinterpret_cast<uint2*>(a.qx + q_dst + c * 64) = hi.u;
+      *reinterpret_cast<uint2*>(a.xl + q_dst + c * 64) = lo.u;
+      slot = slot == 2 ? 0 : slot + 1;
+      continue;
+    }
     float q[4];
     // levels by reciprocal multiply (minmax_level_fast); a lane whose quotient sits on a rounding tie sends its wave through
     // the IEEE division below (about one wave-chunk in 500 on Gaussian rows)
@@ -2827,7 +2856,10 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   const bool use_rows16 = panel_ok && !(x.ascale && a->r > 0) && rows16 && xgrid < 2 * gemm_grid(1 << 30);
   const char* xs_env = getenv("SPQ_XPASS_STREAM");        // 0: the panel kernels, 1 / unset: auto, 16 / 32: forced row count (tuning, tests)
   const int stream16 = xs_env ? atoi(xs_env) : 1;
-  const bool stream_ok = panel_ok && stream16 && a->r > 0 && !x.limbs && !x.lora_fq && !x.ascale;
+  // (the limb form of the streaming kernel has no LayerNorm prologue; SPQ_XPASS_STREAM_LIMBS=0 keeps limbs on the panel kernels)
+  const char* sl_env = getenv("SPQ_XPASS_STREAM_LIMBS");
+  const bool stream_limbs = !(sl_env && sl_env[0] == '0');
+  const bool stream_ok = panel_ok && stream16 && a->r > 0 && (!x.limbs || (stream_limbs && !a->ln_weight && a->quantize_input)) && !x.lora_fq && !x.ascale;
   const char* re = getenv("SPQ_PREP_ROLE");                // read per call (tests flip it)
   const int role_env = (re && re[0] == '0') ? 0 : 1;
   bool role_prep = false;                                  // the row work as extra workgroups of the streaming activation launch
@@ -2887,6 +2919,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
         SPQ_XS_ATTR(16, 0, true); SPQ_XS_ATTR(16, 1, true); SPQ_XS_ATTR(16, 2, true);
         SPQ_XS_ATTR(32, 0, false); SPQ_XS_ATTR(32, 1, false); SPQ_XS_ATTR(32, 2, false);
         SPQ_XS_ATTR(32, 0, true); SPQ_XS_ATTR(32, 1, true); SPQ_XS_ATTR(32, 2, true);
+        SPQ_XS_ATTR(16, 3, false); SPQ_XS_ATTR(32, 3, false);
 #undef SPQ_XS_ATTR
       }
       // 32-row workgroups halve the FQ(A)^T traffic through L2; taken once they still cover every CU
@@ -2896,20 +2929,23 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
         if (AttrOnce once(8); once.first) {
 #define SPQ_XSP_ATTR(R, A8, MODE) (void)hipFuncSetAttribute((const void*)xpass_stream_prep_kernel<R, A8, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, xs_lds(R))
           SPQ_XSP_ATTR(16, 0, 0); SPQ_XSP_ATTR(16, 1, 0); SPQ_XSP_ATTR(16, 2, 1); SPQ_XSP_ATTR(32, 0, 0); SPQ_XSP_ATTR(32, 1, 0); SPQ_XSP_ATTR(32, 2, 1);
+          SPQ_XSP_ATTR(16, 3, 0); SPQ_XSP_ATTR(32, 3, 0);
 #undef SPQ_XSP_ATTR
         }
         const int R = r32 ? 32 : 16;
         const unsigned nx = (unsigned)((a->M + R - 1) / R);
         const unsigned nrow = (unsigned)((pad_to(a->N, GN) + R / 4 - 1) / (R / 4));
 #define SPQ_XSP_LAUNCH(R, A8, MODE) xpass_stream_prep_kernel<R, A8, MODE><<<nx + nrow, R * 16, xs_lds(R), st>>>(x, pa, (int)nx)
-        if (r32) { if (x.a8 == 0) SPQ_XSP_LAUNCH(32, 0, 0); else if (x.a8 == 1) SPQ_XSP_LAUNCH(32, 1, 0); else SPQ_XSP_LAUNCH(32, 2, 1); }
+        if (x.limbs) { if (r32) SPQ_XSP_LAUNCH(32, 3, 0); else SPQ_XSP_LAUNCH(16, 3, 0); }
+        else if (r32) { if (x.a8 == 0) SPQ_XSP_LAUNCH(32, 0, 0); else if (x.a8 == 1) SPQ_XSP_LAUNCH(32, 1, 0); else SPQ_XSP_LAUNCH(32, 2, 1); }
         else { if (x.a8 == 0) SPQ_XSP_LAUNCH(16, 0, 0); else if (x.a8 == 1) SPQ_XSP_LAUNCH(16, 1, 0); else SPQ_XSP_LAUNCH(16, 2, 1); }
 #undef SPQ_XSP_LAUNCH
       } else
 #define SPQ_XS_LAUNCH(R, A8, LN) xpass_stream_kernel<R, A8, LN><<<(unsigned)((a->M + R - 1) / R), R * 16, xs_lds(R), st>>>(x)
 #define SPQ_XS_PICK(R) do { if (ln) { if (x.a8 == 0) SPQ_XS_LAUNCH(R, 0, true); else if (x.a8 == 1) SPQ_XS_LAUNCH(R, 1, true); else SPQ_XS_LAUNCH(R, 2, true); } \
                             else { if (x.a8 == 0) SPQ_XS_LAUNCH(R, 0, false); else if (x.a8 == 1) SPQ_XS_LAUNCH(R, 1, false); else SPQ_XS_LAUNCH(R, 2, false); } } while (0)
-      if (r32) SPQ_XS_PICK(32); else SPQ_XS_PICK(16);
+      if (x.limbs) { if (r32) SPQ_XS_LAUNCH(32, 3, false); else SPQ_XS_LAUNCH(16, 3, false); }
+      else if (r32) SPQ_XS_PICK(32); else SPQ_XS_PICK(16);
 #undef SPQ_XS_PICK
 #undef SPQ_XS_LAUNCH
     } else if (x.ascale && a->r > 0) xpass_panel16_kernel<<<xgrid, 512, XP16_LDS, st>>>(x);

@@ -145,3 +145,60 @@ def test_scales_outside_the_reciprocal_range(pkg):
     for m in ("32", "16"):
         assert torch.equal(torch.isnan(out[m]), torch.isnan(out["0"]))
         assert torch.equal(torch.nan_to_num(out[m], nan=0.0), torch.nan_to_num(out["0"], nan=0.0))
+
+
+# ---- the limb form (A8 = 3): any other input quantizer on the streaming kernel, against the panel kernels it replaces
+def build_q(pkg, M, K, N, r, bits, qtype, per_channel=True, symmetric=True, seed=0):
+    from llm_qat_on_gpt2_amd import synthetic as S
+    W, bias, A, B, x0, x1 = S.make_workload(M, K, N, max(r, 1), seed=seed, batch=1)
+    layer = pkg.SPLinearWithLoRA(K, N, [bits, 32], {bits: r, 32: 0}, {bits: max(r, 1), 32: 0}, {bits: qtype, 32: None}, per_channel=per_channel)
+    key = f"{bits}bit"
+    with torch.no_grad():
+        layer.linear.weight.copy_(W); layer.linear.bias.copy_(bias)
+        layer.lora_adapters[key].lora_A.copy_(A); layer.lora_adapters[key].lora_B.copy_(B)
+    layer = layer.to(DEV).eval()
+    layer.set_precision(bits)
+    if not symmetric:
+        for q in (layer.quantizers_input[key], layer.quantizers_weight[key], layer.lora_adapters[key].quantize_A, layer.lora_adapters[key].quantize_B):
+            q.symmetric = False
+    pkg.calibrate_layer(layer, bits, [x0.to(DEV), x1.to(DEV)])
+    return layer, x0.to(DEV)
+
+
+LIMB_CASES = [
+    # M,    K,    N,   r,  bits, qtype,   per_channel, symmetric
+    (8192, 1024, 256, 64, 6, "log", True, True),          # config 5's layers: 32-row workgroups
+    (4100, 768, 128, 64, 6, "log", True, True),           # ragged M, 16-row workgroups
+    (512, 4096, 128, 64, 4, "log", True, True),           # 64 chunks through the ring
+    (2048, 64, 128, 16, 8, "log", False, True),           # one chunk, per-tensor range
+    (2048, 128, 128, 64, 10, "log", True, True),          # > 8 bits: no level table
+    (4096, 256, 128, 32, 4, "minmax", True, False),       # asymmetric min-max
+    (4096, 256, 128, 32, 16, "minmax", True, True),       # 16-bit min-max: limbs
+    (16432, 256, 128, 16, 5, "log", True, False),         # asymmetric log, M >= 16384
+]
+
+
+@pytest.mark.parametrize("case", LIMB_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_limb_form_matches_the_panel_kernels(pkg, case):
+    M, K, N, r, bits, qtype, pc, sym = case
+    layer, x = build_q(pkg, M, K, N, r, bits, qtype, pc, sym)
+    old = os.environ.get("SPQ_XPASS_STREAM_LIMBS")
+    try:
+        with torch.no_grad():
+            os.environ["SPQ_XPASS_STREAM_LIMBS"] = "0"
+            y_panel = layer(x).clone()
+            assert layer._last_path == pkg._lib.PATH_F16X3
+            os.environ.pop("SPQ_XPASS_STREAM_LIMBS")
+            y_stream = layer(x).clone()
+            layer.cache_operands = False                   # + the weight rows as extra workgroups of the same launch
+            y_role = layer(x).clone()
+    finally:
+        if old is None:
+            os.environ.pop("SPQ_XPASS_STREAM_LIMBS", None)
+        else:
+            os.environ["SPQ_XPASS_STREAM_LIMBS"] = old
+    if M < 16384:                                  # same k-partition of the LoRA-down sum as the 16-row panel kernel: bit-identical
+        assert torch.equal(y_stream, y_panel), f"max abs diff {float((y_stream - y_panel).abs().max()):.3e}"
+    else:                                          # the 32-row panel kernel sums the LoRA-down product in another order
+        assert_close_y(y_stream, y_panel, "limb stream vs panel", 1e-6)
+    assert torch.equal(y_role, y_stream)
