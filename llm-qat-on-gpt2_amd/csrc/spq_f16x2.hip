@@ -2320,8 +2320,6 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
 #endif
 }
 
-#include "spq_gemm_pp.h"
-
 constexpr int U8_SLOT_A = GM * 64;                         // 16 KB (BASE: 256 x 64 B;  LORA: 256 x 32 fp16)
 constexpr int U8_SLOT_B = GN * 128;                        // 16 KB per limb (BASE: 128 x 64 fp16; LORA: 128 x 32 fp16 = 8 KB used)
 constexpr int U8_SLOT = U8_SLOT_A + 2 * U8_SLOT_B;         // 48 KB

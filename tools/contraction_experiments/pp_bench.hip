@@ -1,13 +1,16 @@
 // The ping-pong contraction kernel (csrc/spq_gemm_pp.h) against the 128x128 kernel: bit-identity of the outputs on random operands
 // and interleaved timing at a given shape (kernel tuning only).
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off [-DPP_DIAG=<bits>] [-DPP_NT=<4|6>] tools/pp_bench.hip -o tools/pp_bench
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off [-DPP_DIAG=<bits>] [-DPP_NT=<4|6>] tools/contraction_experiments/pp_bench.hip -o tools/pp_bench
 //   tools/pp_bench [M N K R [AL]]
 #include <stdarg.h>
 #include <vector>
 #include <algorithm>
 #include <random>
 #include <string.h>
-#include "../llm-qat-on-gpt2_amd/csrc/spq_f16x2.hip"
+#include "../../llm-qat-on-gpt2_amd/csrc/spq_f16x2.hip"
+namespace spq {
+#include "spq_gemm_pp.h"
+}
 #ifndef PP_NT
 #define PP_NT 6
 #endif
@@ -104,6 +107,9 @@ template <int AL> int run(int M, int N, int K, int R) {
         d[0] += (double)(o[1] - o[0]); d[1] += (double)(o[2] - o[1]); d[2] += (double)(o[3] - o[2]); d[3] += (double)(o[4] - o[3]);
         d[4] += (double)(o[5] - o[4]); d[5] += (double)(o[12] - o[5]); d[6] += (double)(o[12] - o[0]);
       }
+      if (PP_DIAG & 8) { double a = 0, b = 0; for (unsigned bb = 0; bb < grid1; ++bb) for (int w = 4 * grp; w < 4 * grp + 4; ++w) { a += (double)h[((size_t)bb * 8 + w) * 16 + 8]; b += (double)h[((size_t)bb * 8 + w) * 16 + 9]; }
+        const double st = (double)nt1 / grid1 * ((R ? Rp / 64 * 4 : 0) + (AL == 1 ? Kp / 32 : Kp / 64 * 4));
+        printf("group %d per stage: at the barrier %.0f | barrier -> MFMAs done %.0f\n", grp, a / nw / st, b / nw / st); }
       printf("group %d coarse stamps (cycles per wave): prologue %.0f | tile 0 stages %.0f, epilogue %.0f | tile 1 stages %.0f, epilogue %.0f | exit %.0f || total %.0f\n", grp,
              d[0] / nw, d[1] / nw, d[2] / nw, d[3] / nw, d[4] / nw, d[5] / nw, d[6] / nw);
     }
@@ -114,8 +120,8 @@ template <int AL> int run(int M, int N, int K, int R) {
     hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
     double d[3] = {0, 0, 0};
     for (unsigned b = 0; b < grid1; ++b) for (int lw = 0; lw < 4; ++lw) for (int i = 0; i < 3; ++i) d[i] += (double)h[((size_t)grid1 * 8 + (size_t)b * 4 + lw) * 16 + i];
-    const double nl = (double)grid1 * 4, halves = 2.0 * (double)nt1 / grid1 * ((R ? Rp / 64 * 4 : 0) + (AL == 1 ? Kp / 32 : Kp / 64 * 4));
-    printf("loader waves (cycles per half stage): at the barrier %.0f | issuing %d pieces %.0f | waiting for the previous half %.0f\n", d[0] / nl / halves,
+    const double nl = (double)grid1 * 4, halves = 1.0 * (double)nt1 / grid1 * ((R ? Rp / 64 * 4 : 0) + (AL == 1 ? Kp / 32 : Kp / 64 * 4));
+    printf("loader waves (cycles per stage): at the barrier %.0f | issuing 2 x %d pieces %.0f | waiting for the previous stage %.0f\n", d[0] / nl / halves,
            PPCfg<PP_NT>::P, d[1] / nl / halves, d[2] / nl / halves);
   }
 #endif

@@ -461,6 +461,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_pp_kernel(GemmF16Args g) {
 // landed before they arrive at b_k+1: stage s is complete in LDS at b_2s.  Same arithmetic and order per output as the other
 // f16 kernels: bit-identical results.
 // =====================================================================================================================
+#ifndef LC_WIN
+#define LC_WIN 3
+#endif
 template <int NT> struct LCCfg {
   using C = PPCfg<NT>;
   static constexpr int RIV_OFF = C::EPI_OFF + 8 * EPI_WAVE;  // two 1-KB blocks (tile parity): rowinv of the tile's 256 rows
@@ -554,13 +557,17 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
     };
     setup_src();
     // one half of the cursor's stage; with the first half of a tile's first stage loader 0 also stages the tile's LoRA row scales
+    int n_issued = 0;
     auto issue_half = [&]() {
       if (ip >= nwg) return false;
+      const bool skip = (PP_DIAG & 1) && n_issued >= 4;
+      ++n_issued;
       const unsigned slot_base = lds0 + (unsigned)islot * C::STAGE;
       const unsigned voff = cur_lora ? voffR : voffK;
       if (it == 0 && ihalf == 0 && lw == 0 && nls > 0)
         pp_glds16((const void*)(p_riv + (uint64_t)ibm * 4u), (unsigned)lane * 16u, lds0 + L::RIV_OFF + (unsigned)(itile & 1) * 1024u);
-      if (ihalf == 0) {
+      if (skip) { }
+      else if (ihalf == 0) {
 #pragma unroll
         for (int i = 0; i < C::P; ++i) pp_glds16((const void*)src[0][i], voff, slot_base + pdst[0][i]);
       } else {
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
       if (more) issue_half();
       PP_LSTAMP(t2);
       // stage k+1 (issued one barrier interval ago) has landed before this wave arrives at b_k+1: all but the 2 P pieces just issued
-      if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * C::P) : "memory");
+      if (more && !(PP_DIAG & 1)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * C::P) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       PP_LSTAMP(t3);
       if (PP_DIAG & 32) { l_bar += t1 - t0; l_iss += t2 - t1; l_wait += t3 - t2; }
@@ -620,7 +627,6 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
 
   // ================================================== compute ==================================================
   const int wm = w >> 1, wn = w & 1;                        // 4 (M) x 2 (N) waves, 64 x 16 NT outputs each
-  const int grp = w >> 2;
   const int l15 = lane & 15, q4 = lane >> 4;
   const float lora_to_base = (AL == 2) ? g.xscale[0] : 1.f;
   const float out_scale = (AL == 2) ? g.xscale[1] : 1.f;
@@ -691,16 +697,17 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
         for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
   };
 
-  if (grp) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }     // group 1 runs one barrier behind (consumes b_0)
   int slot = 0, ct = 0, tile_i = 0;
-  int pbm = bm, pbn = bn;                                    // group 0: the finished tile whose outputs are still in acc
-  bool pending = false;
+  unsigned long long c_prev = 0; (void)c_prev;
   PP_CSTAMP(0); cs_n = 2;
 #pragma clang loop unroll(disable)
   while (true) {
     const bool two = pp_two<AL>(ct, nls);
-    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");      // stage start: the stage is complete in LDS
-    if (pending) { epilogue(pbm, pbn); pending = false; PP_CSTAMP(1); cs_n += 2; }      // group 0: behind its start barrier
+    if (PP_DIAG & 8) asm volatile("s_nop 0" :: "v"(acc[3][NT - 1][0]), "v"(acc[0][0][0]) : "memory");
+    PP_STAMP(c0);
+    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");      // b_s: the stage is complete in LDS
+    PP_STAMP(c1);
+    if (PP_DIAG & 8) { cs[8] += c1 - c0; if (c_prev) cs[9] += c0 - c_prev; c_prev = c1; }
     const char* sb = smem + slot * C::STAGE;
     if (ct == nls && nls > 0) {                              // LoRA partial sums -> units of the base sum: * 2^-g[m]
       const char* rb = smem + L::RIV_OFF + (tile_i & 1) * 1024 + (wm * 64 + 4 * q4) * 4;
@@ -717,40 +724,39 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
       }
     }
     if (!(PP_DIAG & 2)) {
-      f16x8 fa[4], bh0, bl0, bh1, bl1;
+      // A fragments once per stage; the N fragments through a window of LC_WIN (B-hi, B-lo) pairs: the reads of pair tn + LC_WIN - 1
+      // travel under the MFMAs of pairs tn .. tn + LC_WIN - 2
+      f16x8 fa[4], bh[LC_WIN], bl[LC_WIN];
 #pragma unroll
       for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const f16x8*>(sb + a_rd + t * 1024);
-      bh0 = *reinterpret_cast<const f16x8*>(sb + b_rd);
-      if (two) bl0 = *reinterpret_cast<const f16x8*>(sb + b_rd + C::B_BYTES);
+#pragma unroll
+      for (int j = 0; j < LC_WIN - 1; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(sb + b_rd + j * 1024);
+        if (two) bl[j] = *reinterpret_cast<const f16x8*>(sb + b_rd + C::B_BYTES + j * 1024);
+      }
 #pragma unroll
       for (int tn = 0; tn < NT; ++tn) {
-        if (tn == NT / 2) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // mid-stage barrier
-        if (tn + 1 < NT) {                                     // the next pair's reads travel under this pair's MFMAs
-          bh1 = *reinterpret_cast<const f16x8*>(sb + b_rd + (tn + 1) * 1024);
-          if (two) bl1 = *reinterpret_cast<const f16x8*>(sb + b_rd + C::B_BYTES + (tn + 1) * 1024);
+        if (tn + LC_WIN - 1 < NT) {
+          bh[(tn + LC_WIN - 1) % LC_WIN] = *reinterpret_cast<const f16x8*>(sb + b_rd + (tn + LC_WIN - 1) * 1024);
+          if (two) bl[(tn + LC_WIN - 1) % LC_WIN] = *reinterpret_cast<const f16x8*>(sb + b_rd + C::B_BYTES + (tn + LC_WIN - 1) * 1024);
         }
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], bh0, acc[tm][tn], 0, 0, 0);
+        for (int tm = 0; tm < 4; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], bh[tn % LC_WIN], acc[tm][tn], 0, 0, 0);
         if (two) {
 #pragma unroll
-          for (int tm = 0; tm < 4; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], bl0, acc[tm][tn], 0, 0, 0);
+          for (int tm = 0; tm < 4; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], bl[tn % LC_WIN], acc[tm][tn], 0, 0, 0);
         }
-        bh0 = bh1; bl0 = bl1;
       }
-    } else { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    }
     slot = slot == 2 ? 0 : slot + 1;
     if (++ct < T) continue;
-    // ---- the tile is complete ----
+    // ---- the tile is complete: its stores are issued and left behind (no vector-memory load follows them in this wave) ----
     PP_CSTAMP(0);
-    if (grp) { epilogue(bm, bn); PP_CSTAMP(1); cs_n += 2; }   // group 1: before its next start barrier
-    else { pending = true; pbm = bm; pbn = bn; }              // group 0: after it (both epilogues in one barrier interval)
+    epilogue(bm, bn);
+    PP_CSTAMP(1); cs_n += 2;
     p += gstride; ++tile_i; ct = 0;
     if (p >= nwg) break;
     tile_of(p, bm, bn);
-  }
-  if (!grp) {
-    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");      // b_2S
-    epilogue(pbm, pbn); PP_CSTAMP(1);
   }
 #if PP_DIAG & 32
   if (g.dbg && lane == 0) {
