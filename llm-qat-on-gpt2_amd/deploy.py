@@ -7,8 +7,12 @@ bit-width holding the WHOLE ``state_dict`` plus config dicts; the evaluation loa
 ``convert_to_int8`` (:5-62) is the abs-max INT8 export of every quantized linear; here its levels come straight out of
 ``spq_fakequant``'s int8 output (one statistics pass + one quantize pass per weight, both HIP).
 """
+import collections
+import io
+import pickle
 import time
 import types
+import zipfile
 
 import torch
 
@@ -98,13 +102,86 @@ def save_sp_checkpoints(model, base_filename, model_config, training_config=None
     return saved
 
 
+# ---- a data-only reader for torch zip checkpoints of any pickle protocol ------------------------------------------------------
+# The reference writes its checkpoints with ``pickle_protocol=4`` (deploy.py:152); torch's ``weights_only`` unpickler refuses that
+# protocol's opcodes, and ``weights_only=False`` would run whatever the file says.  This reader runs nothing from the file: the
+# only globals it resolves are the handful a state dict is made of, and tensor bytes come from the archive's ``data/`` records.
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"): collections.OrderedDict,
+    ("torch._utils", "_rebuild_tensor_v2"): torch._utils._rebuild_tensor_v2,
+    ("torch._utils", "_rebuild_parameter"): torch._utils._rebuild_parameter,
+    ("torch", "Size"): torch.Size,
+}
+_STORAGE_DTYPES = {
+    "FloatStorage": torch.float32, "DoubleStorage": torch.float64, "HalfStorage": torch.float16, "BFloat16Storage": torch.bfloat16,
+    "LongStorage": torch.int64, "IntStorage": torch.int32, "ShortStorage": torch.int16, "CharStorage": torch.int8,
+    "ByteStorage": torch.uint8, "BoolStorage": torch.bool,
+}
+
+
+class _StorageTag:
+    """what ``torch.FloatStorage`` & co. unpickle to: just the dtype of the storage the persistent id refers to"""
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+
+class _DataOnlyUnpickler(pickle.Unpickler):
+    def __init__(self, file, read_record):
+        super().__init__(file)
+        self._read_record = read_record
+        self._storages = {}
+
+    def find_class(self, module, name):
+        if module == "torch" and name in _STORAGE_DTYPES:
+            return _StorageTag(_STORAGE_DTYPES[name])
+        try:
+            return _SAFE_GLOBALS[(module, name)]
+        except KeyError:
+            raise pickle.UnpicklingError(f"checkpoint refers to {module}.{name}, which a state dict has no business with") from None
+
+    def persistent_load(self, pid):
+        # ('storage', <storage type>, key, location, numel): torch.serialization._save
+        if not (isinstance(pid, tuple) and len(pid) == 5 and pid[0] == "storage" and isinstance(pid[1], _StorageTag)):
+            raise pickle.UnpicklingError(f"unexpected persistent id {pid!r}")
+        _, tag, key, _location, numel = pid
+        if key not in self._storages:
+            raw = self._read_record(str(key))
+            nbytes = int(numel) * torch.empty((), dtype=tag.dtype).element_size()
+            if len(raw) < nbytes:
+                raise pickle.UnpicklingError(f"storage {key}: {len(raw)} bytes in the archive, {nbytes} expected")
+            untyped = torch.frombuffer(bytearray(raw[:nbytes]) if nbytes else bytearray(1), dtype=torch.uint8)[:nbytes].untyped_storage()
+            self._storages[key] = torch.storage.TypedStorage(wrap_storage=untyped, dtype=tag.dtype, _internal=True)
+        return self._storages[key]
+
+
+def load_checkpoint_data_only(path):
+    """Read a ``torch.save`` zip archive (any pickle protocol) without executing anything from it: dicts, lists, numbers,
+    strings and CPU tensors only; any other global in the pickle stream raises ``pickle.UnpicklingError``."""
+    with zipfile.ZipFile(path) as z:
+        names = z.namelist()
+        pkl = [n for n in names if n.endswith("/data.pkl") or n == "data.pkl"]
+        if len(pkl) != 1:
+            raise pickle.UnpicklingError(f"{path}: not a torch zip checkpoint (data.pkl entries: {pkl})")
+        prefix = pkl[0][:-len("data.pkl")]
+        if prefix + "byteorder" in names and z.read(prefix + "byteorder").strip() not in (b"little", b""):
+            raise pickle.UnpicklingError(f"{path}: big-endian checkpoint")
+        with z.open(pkl[0]) as f:
+            return _DataOnlyUnpickler(io.BytesIO(f.read()), lambda key: z.read(prefix + "data/" + key)).load()
+
+
 def load_sp_checkpoint(path, device='cuda', target_bits=None, weights_only=True):
     """The evaluation loader (main_sp_eval.py:22-78, deploy.py:185-253): build an ``SPLMHeadModel`` from the checkpoint's
     ``model_config`` with ``per_channel_quantization=False``, ``set_precision(bit_width)``, ``load_state_dict(strict=True)``.
 
-    ``weights_only=True`` executes nothing from the file.  Checkpoints written by the reference itself use pickle protocol 4
-    (deploy.py:152), which torch's safe unpickler refuses; pass ``weights_only=False`` only for a file you wrote yourself."""
-    ck = torch.load(path, map_location='cpu', weights_only=weights_only)
+    ``weights_only=True`` executes nothing from the file: torch's safe unpickler first, and -- for the files the reference itself
+    writes, which use pickle protocol 4 (deploy.py:152) and which that unpickler refuses -- ``load_checkpoint_data_only``."""
+    if weights_only:
+        try:
+            ck = torch.load(path, map_location='cpu', weights_only=True)
+        except pickle.UnpicklingError:
+            ck = load_checkpoint_data_only(path)
+    else:
+        ck = torch.load(path, map_location='cpu', weights_only=False)
     mc = ck['model_config']
     sd = ck.get('model_state_dict', ck)
     n_positions = sd['transformer.wpe.weight'].shape[0] if 'transformer.wpe.weight' in sd else mc.get('n_positions', 1024)

@@ -1,7 +1,11 @@
-"""CPU: the checkpoint wire format -- a file laid out like the reference's ``save_sp_checkpoints`` output
-(deploy.py:143-152; fixture written by the reference itself, tests/golden/make_golden_model.py) loads with ``strict=True``
-into this build's ``SPLMHeadModel`` built the way the evaluation loader builds it (main_sp_eval.py:22-78).  No compute."""
+"""CPU: the checkpoint wire format -- the files of tests/golden are BYTE FOR BYTE what the reference's own
+``save_sp_checkpoints`` wrote (deploy.py:143-152, pickle protocol 4; tests/golden/make_golden_model.py).  They load with
+``strict=True`` into this build's ``SPLMHeadModel`` built the way the evaluation loader builds it (main_sp_eval.py:22-78), through
+``deploy.load_checkpoint_data_only`` -- torch's ``weights_only`` unpickler refuses protocol 4 -- which runs nothing from the
+file.  No compute."""
+import collections
 import os
+import pickle
 
 import pytest
 import torch
@@ -38,6 +42,49 @@ def test_reference_checkpoint_loads_strict(bits):
     assert s.numel() == 1 and z.numel() == 1 and float(s) == 0.0 and abs(float(z) - (-16.609640)) < 1e-5
     qb1 = model.transformer.h[1].mlp.c_fc.lora_adapters["6bit"].quantize_B
     assert tuple(qb1.scale.shape) == (1, 256) and qb1.qparams_for(256)[0] is qb1.scale
+
+
+@pytest.mark.parametrize("bits", [4, 6])
+def test_fixture_is_the_reference_wire_format(bits):
+    """the fixture really is a protocol-4 file that torch's safe loader cannot read, and the data-only reader reads it whole"""
+    from llm_qat_on_gpt2_amd import deploy
+    path = os.path.join(GOLDEN, f"ckpt_sp3_{bits}bit.pth")
+    with pytest.raises(pickle.UnpicklingError):
+        torch.load(path, map_location="cpu", weights_only=True)
+    ck = deploy.load_checkpoint_data_only(path)
+    assert ck["bit_width"] == bits and isinstance(ck["model_state_dict"], collections.OrderedDict) and len(ck["model_state_dict"]) == 564
+    assert all(torch.is_tensor(v) and v.device.type == "cpu" for v in ck["model_state_dict"].values())
+    assert ck["model_config"]["quantizer_per_bit"] == {4: "minmax", 6: "log", 32: None}
+
+
+def test_data_only_reader_round_trip_and_refusals(tmp_path):
+    from llm_qat_on_gpt2_amd import deploy
+    sd = collections.OrderedDict(a=torch.randn(3, 4), b=torch.arange(5), c=torch.nn.Parameter(torch.randn(2)), e=torch.zeros(0),
+                                 v=torch.randn(6)[1:4], h=torch.randn(4).half(), t=torch.tensor([True, False]))
+    ck = {"model_state_dict": sd, "model_config": {"x": 1, "l": [1, 2], "d": {4: "minmax", 32: None}}, "bit_width": 4, "training_config": None}
+    for proto in (2, 4, 5):
+        f = str(tmp_path / f"p{proto}.pth")
+        torch.save(ck, f, pickle_protocol=proto)
+        r = deploy.load_checkpoint_data_only(f)
+        assert list(r["model_state_dict"]) == list(sd) and r["model_config"] == ck["model_config"] and r["training_config"] is None
+        for k in sd:
+            assert r["model_state_dict"][k].dtype == sd[k].dtype and torch.equal(r["model_state_dict"][k], sd[k].detach()), k
+        assert isinstance(r["model_state_dict"]["c"], torch.nn.Parameter)
+
+    class Evil:                                              # anything that is not plain data is refused, nothing runs
+        def __reduce__(self):
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+    g = str(tmp_path / "evil.pth")
+    torch.save({"model_state_dict": sd, "x": Evil()}, g, pickle_protocol=4)
+    with pytest.raises(pickle.UnpicklingError, match="no business"):
+        deploy.load_checkpoint_data_only(g)
+    with pytest.raises(pickle.UnpicklingError):
+        deploy.load_sp_checkpoint(g, device="cpu")
+    assert not (tmp_path / "pwned").exists()
+    with open(tmp_path / "junk.pth", "wb") as fh:
+        fh.write(b"not a zip")
+    with pytest.raises(Exception):
+        deploy.load_checkpoint_data_only(str(tmp_path / "junk.pth"))
 
 
 def test_qparams_for_refuses_non_uniform_odd_shapes():

@@ -503,101 +503,87 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
 
   if (w >= 8) {
     // ================================================ loader ================================================
+    // Hot path per stage: 2 P x (LDS address -> m0, one LDS-DMA, source += 64 B).  Everything else -- which operand, which k block,
+    // which tile -- changes only at SEGMENT boundaries (a tile's thi stages, its tlo stages, its base stages: three per tile at the
+    // headline shape), where next_segment() recomputes the 2 P sources from scratch.  (A generic per-stage cursor cost ~850
+    // scalar cycles per stage, and a wave's scalar stream advances slowly beside two MFMA-streaming waves on its SIMD.)
     const int lw = w - 8;
 #ifdef LC_FAKE128      // timing probe only (wrong data): a piece reads 8 rows x 128 B instead of 16 rows x 64 B
     const int prow = lane >> 3;
     const int pcol = (lane & 7) * 8;
-#elif defined(LC_FAKE1K)   // timing probe only: a piece reads 1 KB of contiguous memory
-    const int prow = 0;
-    const int pcol = lane * 8;
 #else
     const int prow = lane >> 2;
     const int pcol = ((lane & 3) ^ pp_g((prow >> 2) & 3)) * 8;
 #endif
     const unsigned voffK = (unsigned)(prow * g.Kp + pcol) * 2u, voffR = (unsigned)(prow * g.Rp + pcol) * 2u;
-    uint64_t p_qx = (uint64_t)g.qx, p_xl = (uint64_t)g.xl, p_thi = (uint64_t)g.thi, p_tlo = (uint64_t)g.tlo;
-    uint64_t p_whi = (uint64_t)g.Whi, p_wlo = (uint64_t)g.Wlo, p_bhi = (uint64_t)g.Bhi, p_blo = (uint64_t)g.Blo;
+    constexpr int NP = 2 * C::P;
+    uint64_t src[NP];
+    unsigned dstc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int h = i / C::P, ii = i % C::P;
+      const int kd = pp_piece_kind<NT>(4 * h + lw, ii), r0 = 16 * pp_piece_index<NT>(4 * h + lw, ii);
+      dstc[i] = (kd == 0 ? 0u : (kd == 1 ? (unsigned)C::A_BYTES : (unsigned)(C::A_BYTES + C::B_BYTES))) + (unsigned)r0 * 64u;
+    }
     uint64_t p_riv = (uint64_t)g.rowinv;
-    int ldK = g.Kp, ldR = g.Rp;
-    asm volatile("" : "+s"(p_qx), "+s"(p_xl), "+s"(p_thi), "+s"(p_tlo), "+s"(p_whi), "+s"(p_wlo), "+s"(p_bhi), "+s"(p_blo), "+s"(ldK), "+s"(ldR), "+s"(p_riv));
-    int ip = p, it = 0, ibm = bm, ibn = bn, islot = 0, ihalf = 0, itile = 0;
-    uint64_t src[2][C::P];
-    unsigned pdst[2][C::P];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < C::P; ++i) {
-        const int kind = pp_piece_kind<NT>(4 * h + lw, i), idx = pp_piece_index<NT>(4 * h + lw, i);
-        pdst[h][i] = (kind == 0 ? 0u : (kind == 1 ? (unsigned)C::A_BYTES : (unsigned)(C::A_BYTES + C::B_BYTES))) + (unsigned)idx * 1024u;
-      }
-    bool cur_lora = false;
-    auto setup_src = [&]() {
-      const bool lora = it < nls;
-      const int tt = lora ? it : it - nls;
+    asm volatile("" : "+s"(p_riv));
+    int ip = p, ibm = bm, ibn = bn, itile = 0;
+    int seg = 0, seg_left = 0;                               // segment index inside the tile, stages left in it
+    unsigned voff = voffK;
+    // segments of a tile: LoRA blocks (hi: 2 stages, lo: 2 stages) x Rp/64, then AL == 1: one base segment of Kp/32 stages,
+    // AL == 2: per 64-wide block (hi: 2, lo: 2)
+    const int n_lora_seg = (g.Rp / 64) * 2;
+    const int n_seg = n_lora_seg + (AL == 1 ? 1 : (g.Kp / 64) * 2);
+    auto next_segment = [&]() {
+      const bool lora = seg < n_lora_seg;
+      const int sb2 = lora ? seg : seg - n_lora_seg;
       const bool quad = lora || AL == 2;
-      const int k0 = quad ? (tt >> 2) * 64 + (tt & 1) * 32 : tt * 32;
-      const bool lo = quad && (tt & 2);
+      const bool lo = quad && (sb2 & 1);
+      const int k0 = quad ? (sb2 >> 1) * 64 : 0;
+      seg_left = quad ? 2 : g.Kp / 32;
+      // (bit masks, not selects: the compiler turns a select between pointers into a lookup table in scratch memory)
       const uint64_t mL = (uint64_t)0 - (uint64_t)lora, mO = (uint64_t)0 - (uint64_t)lo;
-      const uint64_t Ap = (((p_tlo & mO) | (p_thi & ~mO)) & mL) | (((AL == 2 ? (p_xl & mO) : 0) | (p_qx & ~mO)) & ~mL);
-      const uint64_t Bhp = (p_bhi & mL) | (p_whi & ~mL);
-      const uint64_t Blp = (p_blo & mL) | (p_wlo & ~mL);
-      const int ld = (ldR & (int)mL) | (ldK & ~(int)mL);
-      const uint64_t A = Ap + (uint64_t)(((int64_t)ibm * ld + k0) * 2);
-      const uint64_t Bh = Bhp + (uint64_t)(((int64_t)ibn * ld + k0) * 2);
-      const uint64_t Bl = Blp + (uint64_t)(((int64_t)ibn * ld + k0) * 2);
+      const uint64_t Ap = ((((uint64_t)g.tlo & mO) | ((uint64_t)g.thi & ~mO)) & mL) | ((((AL == 2 ? (uint64_t)g.xl : 0) & mO) | ((uint64_t)g.qx & ~mO)) & ~mL);
+      const uint64_t Bhp = ((uint64_t)g.Bhi & mL) | ((uint64_t)g.Whi & ~mL);
+      const uint64_t Blp = ((uint64_t)g.Blo & mL) | ((uint64_t)g.Wlo & ~mL);
+      const int ld = (g.Rp & (int)mL) | (g.Kp & ~(int)mL);
+      voff = lora ? voffR : voffK;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < C::P; ++i) {
-          const int kind = pp_piece_kind<NT>(4 * h + lw, i), idx = pp_piece_index<NT>(4 * h + lw, i);
-          const uint64_t mA = (uint64_t)0 - (uint64_t)(kind == 0), mH = (uint64_t)0 - (uint64_t)(kind == 1);
-          src[h][i] = ((A & mA) | (((Bh & mH) | (Bl & ~mH)) & ~mA)) + (uint64_t)((int64_t)(16 * idx) * ld * 2);
-        }
-      cur_lora = lora;
+      for (int i = 0; i < NP; ++i) {
+        const int h = i / C::P, ii = i % C::P;
+        const int kd = pp_piece_kind<NT>(4 * h + lw, ii), r0 = 16 * pp_piece_index<NT>(4 * h + lw, ii);
+        const uint64_t mA = (uint64_t)0 - (uint64_t)(kd == 0), mH = (uint64_t)0 - (uint64_t)(kd == 1);
+        const uint64_t base = (Ap & mA) | (((Bhp & mH) | (Blp & ~mH)) & ~mA);
+        const int r = ((ibm & (int)mA) | (ibn & ~(int)mA)) + r0;
+        src[i] = base + (uint64_t)(((int64_t)r * ld + k0) * 2);
+      }
     };
-    setup_src();
-    // one half of the cursor's stage; with the first half of a tile's first stage loader 0 also stages the tile's LoRA row scales
-    int n_issued = 0;
-    auto issue_half = [&]() {
-      if (ip >= nwg) return false;
-      const bool skip = (PP_DIAG & 1) && n_issued >= 4;
-      ++n_issued;
-      const unsigned slot_base = lds0 + (unsigned)islot * C::STAGE;
-      const unsigned voff = cur_lora ? voffR : voffK;
-      if (it == 0 && ihalf == 0 && lw == 0 && nls > 0)
+    next_segment();
+    unsigned slot_base = lds0;
+    int stages_issued = 0;
+    auto issue_stage = [&]() {
+      if (seg == 0 && seg_left == (n_lora_seg ? 2 : (AL == 1 ? g.Kp / 32 : 2)) && lw == 0 && n_lora_seg > 0)   // first stage of a tile
         pp_glds16((const void*)(p_riv + (uint64_t)ibm * 4u), (unsigned)lane * 16u, lds0 + L::RIV_OFF + (unsigned)(itile & 1) * 1024u);
-      if (skip) { }
-      else if (ihalf == 0) {
+      if (!((PP_DIAG & 1) && stages_issued >= 2)) {
 #pragma unroll
-        for (int i = 0; i < C::P; ++i) pp_glds16((const void*)src[0][i], voff, slot_base + pdst[0][i]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < C::P; ++i) pp_glds16((const void*)src[1][i], voff, slot_base + pdst[1][i]);
+        for (int i = 0; i < NP; ++i) pp_glds16((const void*)src[i], voff, slot_base + dstc[i]);
       }
-      if (ihalf == 0) { ihalf = 1; return true; }
-      ihalf = 0;
-      islot = islot == 2 ? 0 : islot + 1;
-      ++it;
-      if (it == T) {
-        it = 0; ip += gstride; ++itile;
-        if (ip < nwg) { tile_of(ip, ibm, ibn); setup_src(); }
-      } else {
-        const int tt = it < nls ? it : it - nls;
-        const bool quad = it < nls || AL == 2;
-        if (it == nls || (quad && !(tt & 1))) setup_src();
-        else {
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < C::P; ++i) src[h][i] += 64;
+      for (int i = 0; i < NP; ++i) src[i] += 64;
+      slot_base = slot_base == lds0 + 2u * C::STAGE ? lds0 : slot_base + C::STAGE;
+      ++stages_issued;
+      if (--seg_left == 0) {
+        if (++seg == n_seg) {
+          seg = 0; ip += gstride; ++itile;
+          if (ip < nwg) tile_of(ip, ibm, ibn);
         }
+        if (ip < nwg) next_segment();
       }
-      return true;
     };
 #ifdef LC_LPRIO
     __builtin_amdgcn_s_setprio(LC_LPRIO);
 #endif
-    issue_half(); issue_half(); issue_half(); issue_half();  // stages 0 and 1
+    issue_stage(); issue_stage();                            // stages 0 and 1
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * C::P) : "memory");  // stage 0 has landed
     unsigned long long l_bar = 0, l_iss = 0, l_wait = 0;
     (void)l_bar; (void)l_iss; (void)l_wait;
@@ -606,8 +592,8 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
       PP_LSTAMP(t0);
       __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");    // b_k: the compute waves have left stage k-1
       PP_LSTAMP(t1);
-      const bool more = issue_half();                                  // stage k+2 -> the slot of stage k-1
-      if (more) issue_half();
+      const bool more = k + 2 < S;
+      if (more) issue_stage();                                         // stage k+2 -> the slot of stage k-1
       PP_LSTAMP(t2);
       // stage k+1 (issued one barrier interval ago) has landed before this wave arrives at b_k+1: all but the 2 P pieces just issued
       if (more && !(PP_DIAG & 1)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * C::P) : "memory");
@@ -723,30 +709,42 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
         }
       }
     }
-    if (!(PP_DIAG & 2)) {
-      // A fragments once per stage; the N fragments through a window of LC_WIN (B-hi, B-lo) pairs: the reads of pair tn + LC_WIN - 1
-      // travel under the MFMAs of pairs tn .. tn + LC_WIN - 2
+    // A fragments once per stage; the N fragments through a window of LC_WIN (B-hi, B-lo) pairs: the reads of pair tn + LC_WIN - 1
+    // travel under the MFMAs of pairs tn .. tn + LC_WIN - 2.  Two-limb and one-limb stages are separate instantiations: with the limb
+    // count a run-time branch the compiler counts one read per pair in its lgkmcnt waits and so waits for the pair issued one
+    // iteration ago instead of two (~80 cycles per pair), and every pair costs two branches in the MFMA stream.
+    // A fragments once per stage; the N fragments through a window of LC_WIN (B-hi, B-lo) pairs: the reads of pair tn + LC_WIN - 1
+    // travel under the MFMAs of pairs tn .. tn + LC_WIN - 2.  The reads are inline asm with counted lgkmcnt waits: left to the
+    // compiler, (a) with the limb count a run-time branch it counts one read per pair and waits for the pair issued ONE iteration
+    // ago instead of two, (b) with both limbs read unconditionally it sinks the B-lo reads into the conditional block that uses
+    // them, right in front of their MFMAs, (c) two instantiations of the body make it keep two accumulator sets.  Both limbs are
+    // read in every stage (a one-limb stage reads a stale B-lo block and ignores it); only the lo MFMAs are conditional.
+    if (!(PP_DIAG & 2) && !((PP_DIAG & 64) && w >= 4)) {
       f16x8 fa[4], bh[LC_WIN], bl[LC_WIN];
+      const unsigned aa = lds0 + (unsigned)slot * C::STAGE + (unsigned)a_rd, ba = lds0 + (unsigned)slot * C::STAGE + (unsigned)b_rd;
+#define LC_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 #pragma unroll
-      for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const f16x8*>(sb + a_rd + t * 1024);
+      for (int t = 0; t < 4; ++t) LC_DSREAD(fa[t], aa, t * 1024);
 #pragma unroll
-      for (int j = 0; j < LC_WIN - 1; ++j) {
-        bh[j] = *reinterpret_cast<const f16x8*>(sb + b_rd + j * 1024);
-        if (two) bl[j] = *reinterpret_cast<const f16x8*>(sb + b_rd + C::B_BYTES + j * 1024);
-      }
+      for (int j = 0; j < LC_WIN - 1; ++j) { LC_DSREAD(bh[j], ba, j * 1024); LC_DSREAD(bl[j], ba, C::B_BYTES + j * 1024); }
 #pragma unroll
       for (int tn = 0; tn < NT; ++tn) {
-        if (tn + LC_WIN - 1 < NT) {
-          bh[(tn + LC_WIN - 1) % LC_WIN] = *reinterpret_cast<const f16x8*>(sb + b_rd + (tn + LC_WIN - 1) * 1024);
-          if (two) bl[(tn + LC_WIN - 1) % LC_WIN] = *reinterpret_cast<const f16x8*>(sb + b_rd + C::B_BYTES + (tn + LC_WIN - 1) * 1024);
-        }
+        constexpr int W1 = LC_WIN - 1;
+        if (tn + W1 < NT) { LC_DSREAD(bh[(tn + W1) % LC_WIN], ba, (tn + W1) * 1024); LC_DSREAD(bl[(tn + W1) % LC_WIN], ba, C::B_BYTES + (tn + W1) * 1024); }
+        const int ahead = (tn + W1 < NT ? tn + W1 : NT - 1) - tn;      // pairs issued behind pair tn
+        if (ahead >= 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], bh[tn % LC_WIN], acc[tm][tn], 0, 0, 0);
         if (two) {
 #pragma unroll
           for (int tm = 0; tm < 4; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tm], bl[tn % LC_WIN], acc[tm][tn], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
+#undef LC_DSREAD
     }
     slot = slot == 2 ? 0 : slot + 1;
     if (++ct < T) continue;
