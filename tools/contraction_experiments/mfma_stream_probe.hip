@@ -17,9 +17,11 @@ __global__ __launch_bounds__(768) void probe(float* out, unsigned long long* cyc
   f32x4 acc[4][6];
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 6; ++j) for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
   if (threadIdx.x >= 512) {                                  // a third wave per SIMD that only takes part in the barriers
-    if (BAR) for (int s = 0; s < stages; ++s) __builtin_amdgcn_s_barrier();
+    if (BAR == 1) for (int s = 0; s < stages; ++s) __builtin_amdgcn_s_barrier();
+    if (BAR == 2) for (int s = 0; s < 2 * stages + 1; ++s) __builtin_amdgcn_s_barrier();
     return;
   }
+  if (BAR == 2 && threadIdx.x >= 256) __builtin_amdgcn_s_barrier();     // group 1 half a stage behind
   const unsigned long long t0 = __builtin_readcyclecounter();
 #define RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 #pragma clang loop unroll(disable)
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(768) void probe(float* out, unsigned long long* cyc
     }
 #pragma unroll
     for (int tn = 0; tn < 6; ++tn) {
+      if (BAR == 2 && tn == 3) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
       if (V >= 1 && tn + 2 < 6) { RD(bh[(tn + 2) % 3], ba, (tn + 2) * 1024); RD(bl[(tn + 2) % 3], ba, 12288 + (tn + 2) * 1024); }
       const int ahead = (tn + 2 < 6 ? tn + 2 : 5) - tn;
       if (V == 0 && tn > 0) { }
@@ -63,27 +66,27 @@ __global__ __launch_bounds__(768) void probe(float* out, unsigned long long* cyc
   }
   asm volatile("s_nop 0" :: "v"(acc[3][5][0]), "v"(acc[0][0][0]) : "memory");
   const unsigned long long t1 = __builtin_readcyclecounter();
+  if (BAR == 2 && threadIdx.x < 256) __builtin_amdgcn_s_barrier();
   float sum = 0.f;
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 6; ++j) for (int e = 0; e < 4; ++e) sum += acc[i][j][e];
   out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
   if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 template <int V, int BAR> void run(int threads, const char* what) {
-  float* out; unsigned long long* cyc; hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8 * 8);
+  float* out; unsigned long long* cyc; hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 12 * 8);
   const int stages = 200;
   for (int rep = 0; rep < 2; ++rep) probe<V, BAR><<<256, threads>>>(out, cyc, stages, 1);
   hipDeviceSynchronize();
-  unsigned long long h[256 * 8]; hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
+  static unsigned long long h[256 * 12]; hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
   double s = 0; const int wpb = threads / 64, cw = wpb > 8 ? 8 : wpb; const int nw = 256 * cw; for (int b = 0; b < 256; ++b) for (int i = 0; i < cw; ++i) s += (double)h[b * wpb + i];
   printf("%-58s compute waves/SIMD %d, barrier %d, threads %d: %.1f cycles per stage of 48 MFMAs per wave = %.1f per MFMA\n", what, (threads > 512 ? 512 : threads) / 256, BAR, threads, s / nw / stages, s / nw / stages / 48);
   hipFree(out); hipFree(cyc);
 }
 int main() {
-  run<1, 0>(256, "V1 free running");
   run<1, 0>(512, "V1 free running");
-  run<1, 1>(256, "V1 + s_barrier per stage");
-  run<1, 1>(512, "V1 + s_barrier per stage");
+  run<1, 1>(512, "V1 + s_barrier per stage (waves in step)");
+  run<1, 2>(512, "V1 + two barriers per stage, groups half a stage apart");
+  run<1, 2>(768, "V1 + two barriers, staggered, + a barrier-only third wave");
   run<1, 1>(768, "V1 + s_barrier per stage + a barrier-only third wave");
-  run<3, 1>(512, "V3 + s_barrier per stage");
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -467,7 +467,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_pp_kernel(GemmF16Args g) {
 template <int NT> struct LCCfg {
   using C = PPCfg<NT>;
   static constexpr int RIV_OFF = C::EPI_OFF + 8 * EPI_WAVE;  // two 1-KB blocks (tile parity): rowinv of the tile's 256 rows
-  static constexpr int LDS = RIV_OFF + 2048;
+  static constexpr int FLAG_OFF = RIV_OFF + 2048;            // per ring slot: FULL counter (+1 per loader wave and fill) at +16 slot,
+  static constexpr int LDS = FLAG_OFF + 128;                 // FREE counter (+1 per compute wave and stage read) at +64 + 16 slot
 };
 
 template <int NT, int AL, int EPI>
@@ -501,6 +502,24 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
   int bm, bn;
   tile_of(p, bm, bn);
 
+  // Hand-off through monotonic counters in LDS instead of workgroup barriers (mfma_stream_probe.hip: a barrier per stage or half stage
+  // costs two MFMA-streaming waves of a SIMD a third of their rate -- 1747 against 1311 cycles per stage -- because it puts them in
+  // step): FULL[slot] += 1 by each loader wave once its pieces of a fill have landed (behind its counted vmcnt), FREE[slot] += 1 by
+  // each compute wave behind its last fragment read of a stage (the LDS executes a wave's operations in order).
+  if (tid < 32) *reinterpret_cast<unsigned*>(smem + L::FLAG_OFF + tid * 4) = 0u;
+  __syncthreads();
+  auto lds_poll = [&](unsigned addr, int target) {           // spin until the counter has reached target (wave-uniform)
+    unsigned v;
+    do {
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+      v = __builtin_amdgcn_readfirstlane(v);
+      if ((int)(v - (unsigned)target) < 0) __builtin_amdgcn_s_sleep(1);
+    } while ((int)(v - (unsigned)target) < 0);
+  };
+  auto lds_add1 = [&](unsigned addr) {                       // one lane adds 1, no return value, no wait
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(1u) : "memory");
+  };
+  const unsigned flags = lds0 + L::FLAG_OFF;
   if (w >= 8) {
     // ================================================ loader ================================================
     // Hot path per stage: 2 P x (LDS address -> m0, one LDS-DMA, source += 64 B).  Everything else -- which operand, which k block,
@@ -561,12 +580,21 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
     next_segment();
     unsigned slot_base = lds0;
     int stages_issued = 0;
-    auto issue_stage = [&]() {
+    // a stage is issued in two halves (pieces [0, P) and [P, 2P)) so that the landing of the PREVIOUS stage can be confirmed and
+    // published between them: its copies then have this stage's wait for a free slot plus half an issue to land, and FULL is
+    // published as early as a counted vmcnt allows
+    auto issue_first_half = [&]() {
       if (seg == 0 && seg_left == (n_lora_seg ? 2 : (AL == 1 ? g.Kp / 32 : 2)) && lw == 0 && n_lora_seg > 0)   // first stage of a tile
         pp_glds16((const void*)(p_riv + (uint64_t)ibm * 4u), (unsigned)lane * 16u, lds0 + L::RIV_OFF + (unsigned)(itile & 1) * 1024u);
       if (!((PP_DIAG & 1) && stages_issued >= 2)) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) pp_glds16((const void*)src[i], voff, slot_base + dstc[i]);
+        for (int i = 0; i < C::P; ++i) pp_glds16((const void*)src[i], voff, slot_base + dstc[i]);
+      }
+    };
+    auto issue_second_half = [&]() {
+      if (!((PP_DIAG & 1) && stages_issued >= 2)) {
+#pragma unroll
+        for (int i = C::P; i < NP; ++i) pp_glds16((const void*)src[i], voff, slot_base + dstc[i]);
       }
 #pragma unroll
       for (int i = 0; i < NP; ++i) src[i] += 64;
@@ -583,25 +611,29 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
 #ifdef LC_LPRIO
     __builtin_amdgcn_s_setprio(LC_LPRIO);
 #endif
-    issue_stage(); issue_stage();                            // stages 0 and 1
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * C::P) : "memory");  // stage 0 has landed
     unsigned long long l_bar = 0, l_iss = 0, l_wait = 0;
     (void)l_bar; (void)l_iss; (void)l_wait;
+    int slot_i = 0, use_i = 0;                               // slot of the stage to issue, how often that slot has been filled
 #pragma clang loop unroll(disable)
     for (int k = 0; k < S; ++k) {
       PP_LSTAMP(t0);
-      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");    // b_k: the compute waves have left stage k-1
+      if (use_i > 0 && !(PP_DIAG & (256 | 1024))) lds_poll(flags + 64u + 16u * (unsigned)slot_i, 8 * use_i);      // every compute wave has left the slot's last stage
       PP_LSTAMP(t1);
-      const bool more = k + 2 < S;
-      if (more) issue_stage();                                         // stage k+2 -> the slot of stage k-1
+      issue_first_half();
       PP_LSTAMP(t2);
-      // stage k+1 (issued one barrier interval ago) has landed before this wave arrives at b_k+1: all but the 2 P pieces just issued
-      if (more && !(PP_DIAG & 1)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * C::P) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (k > 0) {                                           // stage k-1 has landed: all but the P pieces just issued
+        if (PP_DIAG & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(C::P) : "memory");
+        lds_add1(flags + 16u * (unsigned)(slot_i == 0 ? 2 : slot_i - 1));
+      }
       PP_LSTAMP(t3);
-      if (PP_DIAG & 32) { l_bar += t1 - t0; l_iss += t2 - t1; l_wait += t3 - t2; }
+      issue_second_half();
+      PP_LSTAMP(t4);
+      if (PP_DIAG & 32) { l_bar += t1 - t0; l_iss += (t2 - t1) + (t4 - t3); l_wait += t3 - t2; }
+      if (++slot_i == 3) { slot_i = 0; ++use_i; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_add1(flags + 16u * (unsigned)(slot_i == 0 ? 2 : slot_i - 1));
 #if PP_DIAG & 32
     if (g.dbg && lane == 0) {
       unsigned long long* o = g.dbg + ((int64_t)gridDim.x * 8 + (int64_t)blockIdx.x * 4 + lw) * 16;
@@ -683,18 +715,22 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
         for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
   };
 
-  int slot = 0, ct = 0, tile_i = 0;
-  unsigned long long c_prev = 0; (void)c_prev;
+  int slot = 0, use = 0, ct = 0, tile_i = 0;
+  unsigned full_ahead = 0;                                   // FULL counter of the next stage's slot as read during this stage
+#ifdef LC_G1PRIO
+  if (w >= 4) __builtin_amdgcn_s_setprio(LC_G1PRIO);         // the younger wave of each SIMD otherwise gets what the older one leaves
+#endif
   PP_CSTAMP(0); cs_n = 2;
 #pragma clang loop unroll(disable)
   while (true) {
     const bool two = pp_two<AL>(ct, nls);
-    if (PP_DIAG & 8) asm volatile("s_nop 0" :: "v"(acc[3][NT - 1][0]), "v"(acc[0][0][0]) : "memory");
-    PP_STAMP(c0);
-    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");      // b_s: the stage is complete in LDS
-    PP_STAMP(c1);
-    if (PP_DIAG & 8) { cs[8] += c1 - c0; if (c_prev) cs[9] += c0 - c_prev; c_prev = c1; }
-    const char* sb = smem + slot * C::STAGE;
+    // every loader wave's pieces of this stage have landed.  The counter was read ahead, in the middle of the previous stage (the
+    // read's latency and its s_waitcnt in front of the stage's first fragment reads cost ~12 % of the loop); if the fill had not
+    // been published by then, poll.
+    if (!(PP_DIAG & (256 | 512))) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if ((int)((unsigned)__builtin_amdgcn_readfirstlane(full_ahead) - (unsigned)(4 * (use + 1))) < 0) lds_poll(flags + 16u * (unsigned)slot, 4 * (use + 1));
+    }
     if (ct == nls && nls > 0) {                              // LoRA partial sums -> units of the base sum: * 2^-g[m]
       const char* rb = smem + L::RIV_OFF + (tile_i & 1) * 1024 + (wm * 64 + 4 * q4) * 4;
 #pragma unroll
@@ -710,16 +746,12 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
       }
     }
     // A fragments once per stage; the N fragments through a window of LC_WIN (B-hi, B-lo) pairs: the reads of pair tn + LC_WIN - 1
-    // travel under the MFMAs of pairs tn .. tn + LC_WIN - 2.  Two-limb and one-limb stages are separate instantiations: with the limb
-    // count a run-time branch the compiler counts one read per pair in its lgkmcnt waits and so waits for the pair issued one
-    // iteration ago instead of two (~80 cycles per pair), and every pair costs two branches in the MFMA stream.
-    // A fragments once per stage; the N fragments through a window of LC_WIN (B-hi, B-lo) pairs: the reads of pair tn + LC_WIN - 1
     // travel under the MFMAs of pairs tn .. tn + LC_WIN - 2.  The reads are inline asm with counted lgkmcnt waits: left to the
     // compiler, (a) with the limb count a run-time branch it counts one read per pair and waits for the pair issued ONE iteration
     // ago instead of two, (b) with both limbs read unconditionally it sinks the B-lo reads into the conditional block that uses
     // them, right in front of their MFMAs, (c) two instantiations of the body make it keep two accumulator sets.  Both limbs are
     // read in every stage (a one-limb stage reads a stale B-lo block and ignores it); only the lo MFMAs are conditional.
-    if (!(PP_DIAG & 2) && !((PP_DIAG & 64) && w >= 4)) {
+    if (!(PP_DIAG & 2)) {
       f16x8 fa[4], bh[LC_WIN], bl[LC_WIN];
       const unsigned aa = lds0 + (unsigned)slot * C::STAGE + (unsigned)a_rd, ba = lds0 + (unsigned)slot * C::STAGE + (unsigned)b_rd;
 #define LC_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
@@ -731,9 +763,18 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
       for (int tn = 0; tn < NT; ++tn) {
         constexpr int W1 = LC_WIN - 1;
         if (tn + W1 < NT) { LC_DSREAD(bh[(tn + W1) % LC_WIN], ba, (tn + W1) * 1024); LC_DSREAD(bl[(tn + W1) % LC_WIN], ba, C::B_BYTES + (tn + W1) * 1024); }
+        if (tn + W1 == NT - 1 && !(PP_DIAG & (256 | 1024))) lds_add1(flags + 64u + 16u * (unsigned)slot);        // behind this wave's last read of the stage
+        if (tn + W1 == NT - 1 && !(PP_DIAG & (256 | 512)))      // ... and the NEXT stage's FULL counter, read ahead
+          asm volatile("ds_read_b32 %0, %1" : "=v"(full_ahead) : "v"(flags + 16u * (unsigned)(slot == 2 ? 0 : slot + 1)) : "memory");
         const int ahead = (tn + W1 < NT ? tn + W1 : NT - 1) - tn;      // pairs issued behind pair tn
-        if (ahead >= 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        // (the ds_add behind the last pair counts in lgkmcnt too: one more operation in flight from there on)
+        const int extra = (tn + W1 >= NT - 1 ? 1 : 0) * ((PP_DIAG & (256 | 1024) ? 0 : 1) + (PP_DIAG & (256 | 512) ? 0 : 1));
+        if (2 * ahead + extra == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else if (2 * ahead + extra == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+        else if (2 * ahead + extra == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if (2 * ahead + extra == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else if (2 * ahead + extra == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if (2 * ahead + extra == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -745,8 +786,8 @@ __global__ __launch_bounds__(768, 3) void gemm_f16x2_lc_kernel(GemmF16Args g) {
         __builtin_amdgcn_sched_barrier(0);
       }
 #undef LC_DSREAD
-    }
-    slot = slot == 2 ? 0 : slot + 1;
+    } else { lds_add1(flags + 64u + 16u * (unsigned)slot); full_ahead = 0; }
+    if (++slot == 3) { slot = 0; ++use; }
     if (++ct < T) continue;
     // ---- the tile is complete: its stores are issued and left behind (no vector-memory load follows them in this wave) ----
     PP_CSTAMP(0);
