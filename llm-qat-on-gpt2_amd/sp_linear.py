@@ -439,9 +439,13 @@ class SPLinearWithLoRA(nn.Module):
         # int8 matrix cores (SPQ_PATH_I8): levels of <= 8 bits x the weight's own integer levels -- one product per algorithmic
         # product at twice the f16 rate -- valid when those levels exist (symmetric minmax weights, <= 8 bit) and the input scale
         # is per tensor (it then leaves the sum).  Measured 50-53 us against ~80 us for the contraction at the c_fc shape.
+        # The byte-level activation operand has no NaN: a NaN activation (whose level the reference keeps NaN, quantization_methods.py
+        # :14-15 on torch.clamp) becomes the level 0 there.  With the LoRA branch active that row still comes out NaN -- the fp32
+        # LoRA-down product t = x . FQ(A) carries it -- but with no LoRA term (calibration_mode, a disabled or rank-0 adapter) the
+        # row would be finite where F.linear gives NaN, so those forwards take the fp16-level path, whose levels do hold a NaN.
         i8_ok = bool(f16_ok and qx.num_bits <= 8 and self.in_features % 4 == 0 and self.in_features <= 4096
                      and qw is not None and qw.quantizer_type == 'minmax' and qw.symmetric and 2 <= qw.num_bits <= 8
-                     and qx.scale.numel() == 1)
+                     and qx.scale.numel() == 1 and use_lora and lora is not None and lora.rank > 0)
         if self.operand_path == _lib.PATH_I8:
             return _lib.PATH_I8 if i8_ok else (_lib.PATH_F16X2 if f16_ok else (_lib.PATH_F16X3 if x3_ok else _lib.PATH_F32))
         if self.operand_path == _lib.PATH_AUTO:
@@ -452,8 +456,8 @@ class SPLinearWithLoRA(nn.Module):
             return _lib.PATH_F16X3 if (x3_ok or f16_ok) else _lib.PATH_F32
         if self.operand_path in (_lib.PATH_F16X2, _lib.PATH_U8X2) and not f16_ok:
             return _lib.PATH_F32            # e.g. calibration forwards (raw x) of a layer pinned to F16X2
-        if self.operand_path == _lib.PATH_U8X2 and qx.num_bits > 8:
-            return _lib.PATH_F16X2
+        if self.operand_path == _lib.PATH_U8X2 and (qx.num_bits > 8 or not (use_lora and lora is not None and lora.rank > 0)):
+            return _lib.PATH_F16X2          # (no LoRA term: a NaN activation must stay visible, see above)
         return self.operand_path
 
     def _operands(self, key, qx, qw, lora, use_lora, quantize_input):

@@ -87,3 +87,33 @@ def test_fused_forward_nan_row(pkg, bits, qtype):
     nan_rows = torch.isnan(yn).all(dim=-1)
     assert int(nan_rows.sum()) == 1 and bool(nan_rows[1, 5])            # the whole row of that token, as F.linear gives
     assert torch.equal(yn[~nan_rows], y[~nan_rows])
+
+
+@pytest.mark.parametrize("path", ["I8", "U8X2", "AUTO"])
+@pytest.mark.parametrize("lora_on", [True, False])
+def test_fused_forward_nan_row_byte_level_paths(pkg, path, lora_on):
+    """the byte-level operand paths (per-tensor input scale: what PATH_AUTO picks for every evaluation-loader model)
+    cannot hold a NaN level.  With the LoRA branch the fp32 LoRA-down product carries the NaN; without it (calibration_mode,
+    disabled adapter) the layer must not take a byte-level path: either way the token's whole output row is NaN, as F.linear's."""
+    from oracle import ref_cpu as O
+    M, K, N, r = 256, 128, 192, 16
+    W, bias, A, B, x0, x1 = O.make_workload(M, K, N, r, seed=5, batch=2)
+    layer = pkg.SPLinearWithLoRA(K, N, [8, 32], {8: r, 32: 0}, {8: r, 32: 0}, {8: "minmax", 32: None}, per_channel=False)
+    with torch.no_grad():
+        layer.linear.weight.copy_(W); layer.linear.bias.copy_(bias)
+        layer.lora_adapters["8bit"].lora_A.copy_(A); layer.lora_adapters["8bit"].lora_B.copy_(B)
+    layer = layer.to(DEV).eval()
+    layer.set_precision(8)
+    pkg.calibrate_layer(layer, 8, [x0.to(DEV), x1.to(DEV)])
+    layer.operand_path = {"I8": pkg._lib.PATH_I8, "U8X2": pkg._lib.PATH_U8X2, "AUTO": pkg._lib.PATH_AUTO}[path]
+    if not lora_on:
+        layer.lora_adapters["8bit"].enabled = False
+    x = x0.clone().to(DEV)
+    with torch.no_grad():
+        y = layer(x)
+        x[1, 5, 9] = float("nan")
+        yn = layer(x)
+    nan_rows = torch.isnan(yn).all(dim=-1)
+    assert int(nan_rows.sum()) == 1 and bool(nan_rows[1, 5])
+    assert not bool(torch.isnan(yn[~nan_rows]).any())
+    assert torch.equal(yn[~nan_rows], y[~nan_rows])
