@@ -204,6 +204,9 @@ def main():
     ap.add_argument("--hoist-weights", action="store_true",
                     help="reuse prepared weight operands across steps (eval-mode behaviour of the module)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--setup-steps", type=int, default=SETUP_STEPS,
+                    help="untimed forwards BEFORE the --warmup steps (workspace growth, code-object load, clock ramp); 0 = the "
+                         "timed region starts after exactly --warmup warm-ups")
     ap.add_argument("--calib-comm", choices=["torch", "capi"], default="torch",
                     help="calibration all-reduce through torch.distributed (backend nccl = RCCL) or through libspq's own "
                          "RCCL binding (spq_comm_init / spq_allreduce_minmax)")
@@ -231,6 +234,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import llm_qat_on_gpt2_amd as pkg
+    from llm_qat_on_gpt2_amd import calibration
     from llm_qat_on_gpt2_amd import synthetic as O   # seeded input generator (the CPU leg's oracle draws the same tensors)
 
     W, bias, A, B, _, _ = O.make_workload(8, K_IN, N_OUT, RANK, seed=0)          # replicated weights
@@ -284,7 +288,7 @@ def main():
         return time.perf_counter() - t0, out
 
     with torch.no_grad():
-        for _ in range(SETUP_STEPS):                       # setup, not warm-up: workspace growth, code-object load, clock ramp
+        for _ in range(max(0, args.setup_steps)):          # setup, not warm-up: workspace growth, code-object load, clock ramp
             y = layer(x)
         for _ in range(args.warmup):
             y = layer(x)
@@ -399,7 +403,7 @@ def main():
         out = {
             "metric": "fused quant-GEMM-LoRA fwd GFLOP/s per GPU, GPT-2 c_fc 768→3072 @ 4-bit",
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "setup_steps": SETUP_STEPS, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "setup_steps": args.setup_steps, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_s,
             "data": "synthetic",
             "config": {"workload": "SPLinearWithLoRA c_fc 768->3072, 4-bit minmax per-channel + LoRA r=64, "
@@ -416,7 +420,9 @@ def main():
                                           "after the region `value` is taken from"},
             "algorithmic_GBps_per_gpu": round(BYTES_PER_STEP * args.steps / elapsed / 1e9, 1),
             "frac_of_hbm_peak": round(BYTES_PER_STEP * args.steps / elapsed / 1e9 / PEAK["hbm_gbs"], 4),
-            "calibration": {"ms": round(calib_ms, 2), "allreduce_elements": exchanged, "comm": args.calib_comm},
+            "calibration": {"ms": round(calib_ms, 2), "allreduce_elements": exchanged, "comm": args.calib_comm,
+                            "allreduce_ms": (None if not exchanged else round(calibration.LAST_EXCHANGE["allreduce_ms"], 4)),
+                            "note": "allreduce_ms: HIP events around the ONE data collective on rank 0 (null at one GPU: no collective)"},
             "with_cached_weight_operands": None if elapsed_cached is None else {
                 "ms_per_step": round(elapsed_cached / args.steps * 1e3, 4),
                 "value": round(world * FLOP_PER_STEP * args.steps / elapsed_cached / 1e9, 1),
@@ -430,7 +436,16 @@ def main():
                          "kernel_launches_timed": len(gemm_ms), "peak_dtype": peak_s, "kernel_ms_avg": round(gemm_avg_ms, 4),
                          "frac_vs_f16_mfma_peak": round(achieved / PEAK["f16"], 4),
                          "kernel_ms_min": round(min(gemm_ms), 4) if gemm_ms else None,
-                         "frac_vs_f32_mfma_peak": round(achieved / PEAK["f32"], 4)},
+                         "frac_vs_f32_mfma_peak": round(achieved / PEAK["f32"], 4),
+                         # the contraction on its OWN flops (2MKN + 2MrN: the LoRA-down product 2MKr runs in the activation pass)
+                         "achieved_own_flops": round((FLOP_PER_STEP - 2 * M_TOKENS * K_IN * RANK) / (gemm_avg_ms * 1e-3) / 1e12, 2) if gemm_avg_ms > 0 else None,
+                         # the rest of a step: activation pass (+ weight rows) and FQ(A)^T -- HBM-bound helpers.  bytes = what they must
+                         # move (x read 4MK, levels written 2MK, t limbs 4Mr + row scales, W read 4NK + limbs written 4NK, A/B small)
+                         "helpers": (lambda hb, hms: {"ms": round(hms, 4), "bytes": hb, "GBps": round(hb / (hms * 1e-3) / 1e9, 1) if hms > 0 else None,
+                                                      "frac_of_hbm_peak": round(hb / (hms * 1e-3) / 1e9 / PEAK["hbm_gbs"], 4) if hms > 0 else None,
+                                                      "note": "ms = ms_per_step - kernel_ms_avg (launch gaps included)"})(
+                             6 * M_TOKENS * K_IN + 4 * M_TOKENS * RANK + 4 * M_TOKENS + (0 if args.hoist_weights else 8 * N_OUT * K_IN + 12 * RANK * (K_IN + N_OUT)),
+                             ms_per_step - gemm_avg_ms)},
         }
         if world == 1 and not args.no_cpu_baseline:
             with torch.no_grad():

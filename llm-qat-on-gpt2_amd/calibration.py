@@ -11,6 +11,8 @@ tensors and need no collective.  Backend: ``nccl`` (= RCCL over xGMI) for GPU te
 """
 from typing import Iterable, List, Optional
 
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -67,6 +69,10 @@ class SpqComm:
         self._h = None
 
 
+# what the last data collective of allreduce_calibration_stats moved and how long it took on this rank (None: no collective ran)
+LAST_EXCHANGE = {"allreduce_ms": None, "elements": 0}
+
+
 def allreduce_calibration_stats(module_or_quantizers, group: Optional[dist.ProcessGroup] = None,
                                 comm: Optional[SpqComm] = None) -> int:
     """Merge the running min/max of every collecting quantizer across ranks with ONE data collective (preceded by a
@@ -114,7 +120,18 @@ def allreduce_calibration_stats(module_or_quantizers, group: Optional[dist.Proce
         return 0
     mins = [q.temp_min.reshape(-1) for q in qs]
     maxs = [q.temp_max.reshape(-1) for q in qs]
-    flat = reduce_max_(torch.cat([-torch.cat(mins), torch.cat(maxs)]))       # max(-min) == -min(min)
+    flat = torch.cat([-torch.cat(mins), torch.cat(maxs)])                    # max(-min) == -min(min)
+    # the collective itself, timed (SURVEY.md 8e asks for its latency): device events on the launch stream for GPU tensors
+    if flat.is_cuda:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reduce_max_(flat)
+        e1.record(); e1.synchronize()
+        LAST_EXCHANGE.update(allreduce_ms=e0.elapsed_time(e1), elements=flat.numel())
+    else:
+        t0 = time.perf_counter()
+        reduce_max_(flat)
+        LAST_EXCHANGE.update(allreduce_ms=(time.perf_counter() - t0) * 1e3, elements=flat.numel())
     half = flat.numel() // 2
     off = 0
     for q in qs:
