@@ -172,9 +172,11 @@ def on_device(device):
     return torch.cuda.device(idx)
 
 
-def workspace(device, nbytes: int, stream: int = None) -> torch.Tensor:
-    """One grow-only scratch buffer per (device, stream); calls on one stream serialise, so layers share it."""
-    key = (device.index, stream_ptr(device) if stream is None else stream)
+def workspace(device, nbytes: int, stream: int = None, slot: int = 0) -> torch.Tensor:
+    """One grow-only scratch buffer per (device, stream, slot); calls on one stream serialise, so layers share it.  Slot 1 is the
+    level matrix a producer layer hands to its consumer (cpt_mlp_forward): the consumer of layer i has read it before the
+    producer of layer i+1 -- later on the same stream -- writes it again."""
+    key = (device.index, stream_ptr(device) if stream is None else stream, slot)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

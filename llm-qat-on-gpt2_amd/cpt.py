@@ -465,12 +465,9 @@ def cpt_mlp_forward(fc_in, fc_out, x, fuse=True):
     lead = tuple(x.shape[:-1])
     x2 = x.detach().contiguous().float().view(-1, fc_in.in_features)
     M, H = x2.shape[0], fc_in.out_features
-    # fc_out's activation operand: a buffer of its own (the shared workspace holds fc_in's operands while fc_in runs)
+    # fc_out's activation operand: the stream's second workspace slot (the first holds fc_in's operands while fc_in runs)
     need = lib.spq_fwd_workspace_bytes(M, H, fc_out.out_features, 0, _QuantGemm.path_for(qi2, fc_out.out_features, True))
-    buf = getattr(fc_out, "_levels_in", None)
-    if buf is None or buf.numel() < need or buf.device != dev:
-        buf = torch.empty(need, dtype=torch.uint8, device=dev)
-        fc_out._levels_in = buf
+    buf = _lib.workspace(dev, need, slot=1)              # shared by every layer pair of the stream, not one buffer per layer
     for layer, qi in ((fc_in, fc_in.quantizer_input), (fc_out, qi2)):
         use_lora = layer.shared_lora.lora_A is not None
         path = _QuantGemm.path_for(qi, layer.out_features, True)

@@ -77,7 +77,7 @@ def test_cpt_mlp_levels_out(pkg, E, H, bits, qtype, M):
         qi2 = fc_out.quantizer_input
         Mtot = x2.shape[0]
         Mp = (Mtot + 255) // 256 * 256
-        buf = fc_out._levels_in
+        buf = pkg._lib.workspace(xd.device, 1, slot=1)          # the stream's level-matrix slot, as the fused call left it
         plane = lambda i: buf[i * Mp * H * 2: (i + 1) * Mp * H * 2].view(torch.float16).view(-1, H)[:Mtot]
         if qtype == "minmax":                                    # integer levels: the quantizer's own level kernel
             lv_ref = qi2.quantize_levels(h)
