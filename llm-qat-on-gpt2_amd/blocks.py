@@ -162,8 +162,13 @@ class SPAttention(nn.Module):
         return self.current_bit_width
 
     def forward(self, hidden_states, attention_mask=None, pre_norm=None):
-        B, T, C = hidden_states.shape
-        q, k, v = self.c_attn(hidden_states, pre_norm=pre_norm).split(self.n_embd, dim=2)
+        return self.c_proj(self.core(self.c_attn(hidden_states, pre_norm=pre_norm)))
+
+    def core(self, qkv):
+        """models_sp.py:61-75: what sits between the two projections (split heads, causal softmax attention, merge heads)."""
+        B, T, _ = qkv.shape
+        C = self.n_embd
+        q, k, v = qkv.split(self.n_embd, dim=2)
         q = q.view(B, T, self.n_head, self.head_dim).transpose(1, 2)
         k = k.view(B, T, self.n_head, self.head_dim).transpose(1, 2)
         v = v.view(B, T, self.n_head, self.head_dim).transpose(1, 2)
@@ -175,8 +180,7 @@ class SPAttention(nn.Module):
             att = (q @ k.transpose(-2, -1)) / (self.head_dim ** 0.5)
             att = att.masked_fill(self.bias[:T, :T].to(att.device) == 0, float('-inf'))
             out = torch.softmax(att, dim=-1) @ v
-        out = out.transpose(1, 2).contiguous().view(B, T, C)
-        return self.c_proj(out)
+        return out.transpose(1, 2).contiguous().view(B, T, C)
 
 
 class SPBlock(nn.Module):

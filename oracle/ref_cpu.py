@@ -335,6 +335,25 @@ def switchable_layernorm(x, weight, bias, eps: float = 1e-5):
     return weight * x_normalized + bias                                        # :109
 
 
+def attention_core(qkv, n_head: int):
+    """SPAttention.forward between its two projections (models_sp.py:61-75): split heads, q k^T / sqrt(d), causal mask,
+    softmax, times v, merge heads."""
+    import math
+    B, T, C3 = qkv.shape
+    C = C3 // 3
+    d = C // n_head
+    q, k, v = qkv.split(C, dim=2)                                              # :62
+    q = q.view(B, T, n_head, d).transpose(1, 2)                                # :64-66
+    k = k.view(B, T, n_head, d).transpose(1, 2)
+    v = v.view(B, T, n_head, d).transpose(1, 2)
+    att = (q @ k.transpose(-2, -1)) / math.sqrt(d)                             # :68
+    mask = torch.tril(torch.ones(T, T))                                        # :50, :69
+    att = att.masked_fill(mask == 0, float('-inf'))                            # :70
+    att = F.softmax(att, dim=-1)                                               # :71
+    out = att @ v                                                              # :72
+    return out.transpose(1, 2).contiguous().view(B, T, C)                      # :73
+
+
 def sp_mlp_forward(x, fc: "OracleLayer", proj: "OracleLayer", calibration_mode: bool = False):
     """SPMLP.forward (models_sp.py:124-128): c_fc -> nn.GELU() (exact erf) -> c_proj."""
     h = F.gelu(fc.forward(x, calibration_mode))

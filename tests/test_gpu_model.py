@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN
+from helpers import GOLDEN, assert_close_y, cosim_block, rows_outside
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -89,16 +89,27 @@ def test_spmodel_stack_against_reference_fixture(pkg, bits):
     with torch.no_grad():
         y, hs = model(ids, output_hidden_states=True)
         assert len(hs) == n_layer + 1
-        # block by block from the reference's own hidden states (a level flip inside a block moves one token row by a step)
-        for i, blk in enumerate(model.h):
-            out = blk(t[f"h_{bits}_{i}"].to(DEV))
-            ref = t[f"h_{bits}_{i + 1}"] if i + 1 < n_layer else None
-            if ref is None:
-                out, ref = model.ln_f(out), t[f"y_{bits}"]
-            frac, worst = rows_off(out, ref, tol)
-            assert frac <= 0.06 and worst < 0.05, f"block {i} @ {bits}-bit: {frac:.3f} of rows off, worst {worst:.3e} rms"
-    frac, worst = rows_off(y, t[f"y_{bits}"], tol)
-    assert frac <= 0.15 and worst < 0.05, f"stack @ {bits}-bit: {frac:.3f} of rows off, worst {worst:.3e} rms"
+    # Exact or explained, block by block down the chain (helpers.cosim_block): every stage of every block meets its bound on
+    # every row given the same input; the oracle's own chain reproduces the reference's hidden states; and a row of the product's
+    # chain that is outside the bound of the reference's has a flipped input level upstream.  No statistical allowance.
+    assert torch.equal(hs[0].cpu(), t[f"h_{bits}_0"]), "embeddings"
+    affected, x_ref, nflips = None, t[f"h_{bits}_0"], 0
+    for i, blk in enumerate(model.h):
+        y_staged, y_oracle, affected, nflip = cosim_block(blk, bits, hs[i], affected_in=affected, x_ref=x_ref)
+        nflips += nflip
+        with torch.no_grad():                                # (the last entry of the hidden states is behind ln_f)
+            assert torch.equal(y_staged if i + 1 < n_layer else model.ln_f(y_staged), hs[i + 1]), f"block {i}: the model's hidden state is not the block's staged output"
+        if i + 1 < n_layer:
+            assert_close_y(y_oracle, t[f"h_{bits}_{i + 1}"], f"block {i} @ {bits}-bit: the oracle's chain against the reference's", tol)
+            off = rows_outside(y_staged, t[f"h_{bits}_{i + 1}"], tol)
+            assert not bool((off & ~affected).any()), f"block {i} @ {bits}-bit: {int((off & ~affected).sum())} rows off with no flipped level upstream"
+        x_ref = y_oracle
+    from oracle import ref_cpu as O
+    lnf = (model.ln_f.weights[str(bits)].detach().cpu(), model.ln_f.biases[str(bits)].detach().cpu(), float(model.ln_f.eps))
+    assert_close_y(O.switchable_layernorm(x_ref, *lnf), t[f"y_{bits}"], f"oracle chain @ {bits}-bit", tol)
+    off = rows_outside(y, t[f"y_{bits}"], tol)
+    assert not bool((off & ~affected).any()), f"stack @ {bits}-bit: {int((off & ~affected).sum())} rows off with no flipped level upstream"
+    print(f"[{bits}-bit stack] rows outside the end-to-end bound: {int(off.sum())} of {off.numel()}, every one downstream of one of {nflips} flipped input levels")
     # precision switching round trip and determinism
     with torch.no_grad():
         model.set_precision(32); model(ids); model.set_precision(bits)
@@ -126,10 +137,27 @@ def test_reference_checkpoint_loads_and_runs(pkg, bits):
     with torch.no_grad():
         hidden = model.transformer(ids)
         logits = model(ids)
-    frac, worst = rows_off(hidden, exp[f"hidden_{bits}"], tol)
-    assert frac <= 0.15 and worst < 0.05, f"{bits}-bit checkpoint: {frac:.3f} of hidden rows off, worst {worst:.3e} rms"
-    frac, worst = rows_off(logits, exp[f"logits_{bits}"], tol)
-    assert frac <= 0.15 and worst < 0.05, f"{bits}-bit checkpoint: {frac:.3f} of logit rows off, worst {worst:.3e} rms"
+    # exact or explained, as in test_spmodel_stack_against_reference_fixture (here the oracle's chain stands in for the reference's
+    # hidden states between the blocks, and is itself checked against the reference's final hidden states and logits)
+    from oracle import ref_cpu as O
+    tr = model.transformer
+    with torch.no_grad():
+        _, hs = tr(ids, output_hidden_states=True)
+    affected, x_ref = None, hs[0].cpu()
+    for i, blk in enumerate(tr.h):
+        y_staged, y_oracle, affected, _ = cosim_block(blk, bits, hs[i], affected_in=affected, x_ref=x_ref)
+        with torch.no_grad():
+            assert torch.equal(y_staged if i + 1 < len(tr.h) else tr.ln_f(y_staged), hs[i + 1])
+        x_ref = y_oracle
+    lnf = (tr.ln_f.weights[str(bits)].detach().cpu(), tr.ln_f.biases[str(bits)].detach().cpu(), float(tr.ln_f.eps))
+    hid_ref = O.switchable_layernorm(x_ref, *lnf)
+    assert_close_y(hid_ref, exp[f"hidden_{bits}"], f"{bits}-bit checkpoint: the oracle's chain against the reference's hidden states", tol)
+    off = rows_outside(hidden, exp[f"hidden_{bits}"], tol)
+    assert not bool((off & ~affected).any()), f"{bits}-bit checkpoint: {int((off & ~affected).sum())} hidden rows off with no flipped level upstream"
+    # lm_head (models_sp.py: tied / untied nn.Linear, not quantized): row-wise, so the same rows
+    assert_close_y(torch.nn.functional.linear(hidden.cpu(), model.lm_head.weight.detach().cpu()), logits, f"{bits}-bit lm_head", tol)
+    off = rows_outside(logits, exp[f"logits_{bits}"], tol)
+    assert not bool((off & ~affected).any()), f"{bits}-bit checkpoint: {int((off & ~affected).sum())} logit rows off with no flipped level upstream"
 
     # INT8 export (deploy.py:5-62): levels from spq_fakequant's int8 output
     got = deploy.convert_to_int8(model)

@@ -88,8 +88,10 @@ def test_linear_shapes_against_oracle(pkg, name, M, K, N, r, bits, qtype, pc):
         assert torch.equal(lv, ol.qx.levels(x1).to(torch.int32)), "activation levels not bit-exact"
     with torch.no_grad():
         y = layer(x1.to(DEV))
+        path_y = layer._last_path
         layer.calibration_mode = True
         base = layer(x1.to(DEV))
+        path_base = layer._last_path
         layer.calibration_mode = False
     tol = 1e-5
     assert_close_y(y, ol.forward(x1), f"{name}.y", tol)
@@ -97,7 +99,9 @@ def test_linear_shapes_against_oracle(pkg, name, M, K, N, r, bits, qtype, pc):
     want = pkg._lib.PATH_F16X2 if (qtype == "minmax" and bits <= 12) else pkg._lib.PATH_F16X3
     if qtype == "minmax" and bits <= 8 and not pc and K % 4 == 0:
         want = pkg._lib.PATH_I8                          # per-tensor input scale: the int8 matrix cores
-    assert layer._last_path == want
+    assert path_y == want
+    # without a LoRA term a byte-level path could not show a NaN activation (tests/test_gpu_nan.py): fp16 levels instead
+    assert path_base == (pkg._lib.PATH_F16X2 if want == pkg._lib.PATH_I8 else want)
     if want == pkg._lib.PATH_F16X3:                      # the always-valid fp32 operands agree too
         layer.operand_path = pkg._lib.PATH_F32
         with torch.no_grad():
