@@ -200,7 +200,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--path", choices=["auto", "f32", "f16x2", "u8x2", "f16x3", "i8"], default="auto")
+    ap.add_argument("--path", choices=["auto", "f32", "f16x2", "f16x3", "i8"], default="auto")
     ap.add_argument("--hoist-weights", action="store_true",
                     help="reuse prepared weight operands across steps (eval-mode behaviour of the module)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -253,7 +253,7 @@ def main():
         layer.lora_adapters[key].lora_A.copy_(A); layer.lora_adapters[key].lora_B.copy_(B)
     layer = layer.to(dev).eval()
     layer.set_precision(BITS)
-    layer.operand_path = {"auto": pkg._lib.PATH_AUTO, "f32": pkg._lib.PATH_F32, "f16x2": pkg._lib.PATH_F16X2, "u8x2": pkg._lib.PATH_U8X2,
+    layer.operand_path = {"auto": pkg._lib.PATH_AUTO, "f32": pkg._lib.PATH_F32, "f16x2": pkg._lib.PATH_F16X2,
                           "f16x3": pkg._lib.PATH_F16X3, "i8": pkg._lib.PATH_I8}[args.path]
     layer.cache_operands = bool(args.hoist_weights)
 
@@ -379,7 +379,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * FLOP_PER_STEP * args.steps / elapsed / 1e9
         gemm_avg_ms = sum(gemm_ms) / max(1, len(gemm_ms))
-        is_f16 = path_used in (pkg._lib.PATH_F16X2, pkg._lib.PATH_U8X2, pkg._lib.PATH_F16X3)
+        is_f16 = path_used in (pkg._lib.PATH_F16X2, pkg._lib.PATH_F16X3)
         is_i8 = path_used == pkg._lib.PATH_I8
         achieved = FLOP_PER_STEP / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms > 0 else 0.0
         peak = PEAK["i8"] if is_i8 else (PEAK["f16"] if is_f16 else PEAK["f32"])

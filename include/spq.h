@@ -48,7 +48,8 @@ enum spq_path {
   SPQ_PATH_AUTO = 0,
   SPQ_PATH_F32 = 1,   /* fp32-input MFMA on dequantised fp32 operands: always valid */
   SPQ_PATH_F16X2 = 2, /* exact integer levels (fp16) x 2-limb fp16 weights on f16 MFMA: minmax, symmetric, bits<=12 */
-  SPQ_PATH_U8X2 = 3,  /* same arithmetic, levels stored as bytes (bits<=8), 3-slot LDS ring; same prepared operands as F16X2 */
+  SPQ_PATH_U8X2 = 3,  /* RETIRED (round 3): the byte-level ring kernel, measured slower than F16X2; spq_linear_lora_fwd returns
+                         SPQ_ERR_UNSUPPORTED for it.  The value stays reserved. */
   SPQ_PATH_F16X3 = 4, /* any input quantizer (log, asymmetric, >12 bit) or none at all (quantize_input = 0: plain fp32
                          activations, e.g. a gradient): FQ(x)*2^G as two fp16 limbs x 2-limb weights, three f16 MFMA
                          products per algorithmic product; operands prepared with sx = 1 (no scale folding) */
@@ -64,6 +65,8 @@ enum spq_stage { SPQ_STAGE_ALL = 0, SPQ_STAGE_ACTIVATIONS = 1, SPQ_STAGE_CONTRAC
 typedef void* spq_stream_t;
 
 int spq_version(void);
+/* Re-read the SPQ_* tuning switches from the environment (they are read once, at the first call; tests flip them in-process). */
+int spq_debug_reload_switches(void);
 const char* spq_last_error(void);
 /* Writes the gcnArchName of the current device ("gfx950:sramecc+:xnack-") into buf. */
 int spq_device_arch(char* buf, int buflen);
@@ -227,14 +230,12 @@ typedef struct spq_fwd_args {
   /* enum spq_epilogue: SPQ_EPILOGUE_GELU stores gelu(y) (exact erf form, nn.GELU() of models_sp.py:107) instead of y --
    * the activation between mlp.c_fc and mlp.c_proj fused into c_fc's store (F16X2 / F16X3 paths). */
   int epilogue;
-  /* optional device {2^S, 2^-S} with (bound of |a_prep|) * 2^S in [2^13, 2^14): the LoRA-down product of the activation
-   * pass then runs on the f16 matrix pipe (two fp16 limbs of x * 2^g[m] per 32-row panel and of a_prep * 2^S) instead of
-   * the fp32-input MFMA.  NULL: fp32-input MFMA. */
+  /* RETIRED (round 3): must be NULL.  (It selected the LoRA-down product on the f16 matrix pipe, tools/variants/xpass_panel16.h.) */
   const float* a_limb_scale;
   /* F16 operand paths, optional: (re)make w_prep / w_rowscale / a_prep / b_prep from the fp32 weights as part of this call
-   * (its buffers must be the ones named above).  In the activation stage only.  The row work is spread over the activation
-   * pass's workgroups when that pass is the 16-row kernel (M < 16384) and each workgroup gets <= 8 rows; otherwise the
-   * ordinary preparation launch is issued first.  SPQ_FUSE_PREPARE=0 always takes the latter. */
+   * (its buffers must be the ones named above).  In the activation stage only.  Where the streaming activation kernel runs
+   * (K % 64 == 0, K <= 1024, rank <= 64) the row work rides in ITS launch as extra workgroups; otherwise the ordinary preparation
+   * launch is issued first. */
   const struct spq_prepare_args* prepare;
   /* F16 / I8 operand paths, optional LayerNorm prologue: with ln_weight / ln_bias [K] set, `x` is the INPUT of
    * the SwitchableLayerNorm that precedes the layer (switchable_batchnorm.py:102-109; models_sp.py:160-171: ln_1 -> c_attn,

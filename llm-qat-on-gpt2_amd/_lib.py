@@ -16,8 +16,8 @@ STAGE_ALL, STAGE_ACTIVATIONS, STAGE_CONTRACTION = 0, 1, 2
 EPILOGUE_NONE, EPILOGUE_GELU = 0, 1
 COMM_ID_BYTES = 128
 LIMB_SCALE_WORKSPACE_BYTES = 16384
-PATH_AUTO, PATH_F32, PATH_F16X2, PATH_U8X2, PATH_F16X3, PATH_I8 = 0, 1, 2, 3, 4, 5
-PATH_NAMES = {1: "f32", 2: "f16x2", 3: "u8x2", 4: "f16x3", 5: "i8"}
+PATH_AUTO, PATH_F32, PATH_F16X2, PATH_F16X3, PATH_I8 = 0, 1, 2, 4, 5    # (3: the former byte-level path, tools/variants/gemm_u8x2.h)
+PATH_NAMES = {1: "f32", 2: "f16x2", 4: "f16x3", 5: "i8"}
 LOG_DIRECT = 2
 QTYPE_CODE = {"minmax": MINMAX, "log": LOG}            # part1 quantizers
 QTYPE_CODE_CPT = {"minmax": MINMAX, "log": LOG_DIRECT}  # part2 quantizers (log without the level round trip)
@@ -70,6 +70,7 @@ SIGNATURES = {
     "spq_prepare_cpt": (_int, [_p, _i64, _i64, _p, _p, _int, _int, _int, _int, _p, _p, _i64, _p, _p, _int, _int, _int, _int, _f,
                                 _p, _int, _int, _p, _sz, _p, _p, _p, _p, _p, _p]),
     "spq_layernorm": (_int, [_p, _i64, _i64, _p, _p, _f, _p, _p]),
+    "spq_debug_reload_switches": (_int, []),
     "spq_version": (_int, []),
     "spq_last_error": (C.c_char_p, []),
     "spq_device_arch": (_int, [C.c_char_p, _int]),
@@ -111,6 +112,16 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def set_switch(name: str, value):
+    """Set (or, with None, unset) one of the library's SPQ_* tuning switches and make the library re-read them: they are read from
+    the environment once, at load time, not per call (spq_debug_reload_switches).  For tests and tools."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    check(load().spq_debug_reload_switches(), "spq_debug_reload_switches")
 
 
 def check(rc, what):

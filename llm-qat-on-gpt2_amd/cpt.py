@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from . import _lib
 from .fake_quantize import LearnableFakeQuantize as _Part1FakeQuantize
 from .fake_quantize import _eps_constants, fake_quantize
-from .sp_linear import _LimbGemm, _MFMA16, _gemm_nt, _gemm_tn, _ones, _limb_scale
+from .sp_linear import _LimbGemm, _gemm_nt, _gemm_tn, _ones, _limb_scale
 
 
 class GradientQuantizer(torch.autograd.Function):
@@ -297,11 +297,11 @@ class _QuantGemm:
 
     @staticmethod
     def path_for(q, N, quantize):
-        if not quantize or (N % 4 != 0 and not _MFMA16):
+        if not quantize:
             return _lib.PATH_F32                       # nothing to quantize (statistics pass / uncalibrated width)
         if q.quantizer_type == 'minmax' and q.symmetric and 2 <= q.num_bits <= 12:
             return _lib.PATH_F16X2
-        return _lib.PATH_F16X3 if (q.num_bits <= 24 and _MFMA16) else _lib.PATH_F32
+        return _lib.PATH_F16X3 if q.num_bits <= 24 else _lib.PATH_F32
 
     def _buffers(self, N, K, r, dev):
         if self.key != (N, K, r, dev):
@@ -365,7 +365,6 @@ class _QuantGemm:
                                                self.w.numel(), self.rowscale.data_ptr(), None, st)
                     _lib.check(rc, "spq_prepare_f16x2(cpt)")
         self.path, self.r = path, r
-        self.a_limb_scale = _limb_scale(ql) if (want_aq_t and r and ql is not None and ql.active()) else None
         self.sig = None if sig is None else (sig, path, qi._epoch, qi.num_bits)
 
     def run(self, x2, bias, q, quantize, want_t=False, gemm_events=None, epilogue=0, levels_out=None, levels_in=None, M=None):
@@ -423,7 +422,7 @@ class _QuantGemm:
             out_symmetric=1 if (lv_q is not None and lv_q.symmetric) else 0, out_limb_scale=_lib.ptr(lv_limb),
             workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
             ev_gemm_begin=gemm_events[0] if gemm_events else None, ev_gemm_end=gemm_events[1] if gemm_events else None,
-            t_out=_lib.ptr(t), lora_on_fq_input=1, a_limb_scale=_lib.ptr(self.a_limb_scale) if r else None)
+            t_out=_lib.ptr(t), lora_on_fq_input=1, a_limb_scale=None)
         with torch.cuda.device(dev):
             rc = lib.spq_linear_lora_fwd(ctypes.byref(args), st)
         _lib.check(rc, "spq_linear_lora_fwd(cpt)")
@@ -454,7 +453,7 @@ def cpt_mlp_forward(fc_in, fc_out, x, fuse=True):
     qi2 = fc_out.quantizer_input
     ok = (fuse and not torch.is_grad_enabled() and x.is_cuda and x.numel() > 0 and _chain_ready(fc_in, bits) and _chain_ready(fc_out, bits)
           and qi2.quantizer_type in _lib.QTYPE_CODE_CPT and fc_in.out_features % 64 == 0
-          and fc_in.out_features == fc_out.in_features and _MFMA16 and os.environ.get("SPQ_GEMM_T128", "1") != "0"
+          and fc_in.out_features == fc_out.in_features
           and _QuantGemm.path_for(fc_in.quantizer_input, fc_in.out_features, True) != _lib.PATH_F32
           and _QuantGemm.path_for(qi2, fc_out.out_features, True) != _lib.PATH_F32)
     if not ok:

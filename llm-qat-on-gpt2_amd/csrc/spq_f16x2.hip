@@ -45,10 +45,40 @@ constexpr int XR = 32, XK = 64;                // activation-pass tile: rows per
 
 struct F16x2Layout {                            // workspace carve-up, all offsets 256-B aligned
   int64_t Mp, Kp, Rp;
-  size_t off_qx, off_xl, off_thi, off_tlo, off_rowinv, total;
+  size_t off_qx, off_xl, off_thi, off_tlo, off_rowinv, off_skcnt, off_skpart, total;
 };
 
-static F16x2Layout make_layout(int64_t M, int64_t K, int64_t r) {
+// Split-K of the contraction (gemm_f16x2_t128_kernel): how many workgroups share a tile's k range.  nwg 128 x 128 tiles of T
+// stages each on `slots` resident workgroups (three per CU).  One workgroup's stage takes ~1.2 us + ~0.45 us per workgroup
+// resident on its CU (they share the CU's copy path) and a unit costs about three stages on top of its own (operand fetch,
+// epilogue or partial-sum exchange): take the S in 1..4 with the smallest estimate, S > 1 only if it wins by 10 %.
+// Measured (tools/config_bench.py, M = 8192, contraction alone): K = 3072, N = 768 (384 tiles x 50 stages) 63 -> 47 us with S = 2,
+// as estimated; K = 768, N = 768 (14 stages) 29.5 -> 29 us -- launch, fill / drain and the exchange are what is left of a unit
+// that short -- and K = 4096, N = 1024 on the three-product path (512 tiles x 130 stages) S = 3 = two rounds of units: 413 ->
+// 431 us.  Hence: the automatic choice keeps every unit resident at once (one round) and at least 12 stages long; SPQ_SPLIT_K=2..4
+// forces S wherever it is legal (>= 4 stages per unit, the LoRA stages within the first unit, at most two rounds).
+static int t128_split(int64_t nwg, int T, int nl, int64_t slots, int forced) {
+  if (forced == 0 || nwg <= 0 || nwg >= slots) return 1;
+  int best = 1; double best_t = 0;
+  for (int S = 1; S <= 4; ++S) {
+    const int share = (T + S - 1) / S;
+    if (S > 1 && (share < 4 || nl > share || nwg * S > 2 * slots)) break;
+    if (forced > 1) { if (S == forced) return S; continue; }
+    if (S > 1 && (share < 12 || nwg * S > slots)) break;
+    const double per_cu = (double)(nwg * S) / (double)(slots / 3);
+    const double t = (double)(share + 3) * (1.2 + 0.45 * per_cu);
+    if (S == 1) best_t = t;
+    else if (t < 0.9 * best_t) { best = S; best_t = t; }
+  }
+  return best;
+}
+constexpr int SK_MAX_UNITS = 2 * 3 * 512;        // workspace bound: units <= 2 x slots, slots <= 3 x 512 CUs
+static int64_t sk_reserve_units(int64_t M, int64_t N) {
+  const int64_t nwg = (pad_to(M, 256) / 128) * (pad_to(N, 128) / 128);
+  return nwg >= 3 * 512 ? 0 : std::min<int64_t>(4 * nwg, SK_MAX_UNITS);
+}
+
+static F16x2Layout make_layout(int64_t M, int64_t K, int64_t r, int64_t N = 0) {
   F16x2Layout L;
   L.Mp = pad_to(M, GM); L.Kp = pad_to(K, GK); L.Rp = r > 0 ? pad_to(r, GK) : 0;
   size_t o = 0;
@@ -57,11 +87,15 @@ static F16x2Layout make_layout(int64_t M, int64_t K, int64_t r) {
   L.off_thi = o; o += pad_to((size_t)L.Mp * L.Rp * 2, 256);
   L.off_tlo = o; o += pad_to((size_t)L.Mp * L.Rp * 2, 256);
   L.off_rowinv = o; o += pad_to((size_t)L.Mp * 4, 256);
+  // split-K scratch: {tickets, done} per tile, then one 64-KB register image per unit (N = 0: a layout without it)
+  const int64_t sku = N > 0 ? sk_reserve_units(M, N) : 0;
+  L.off_skcnt = o; o += sku ? 8192 : 0;
+  L.off_skpart = o; o += (size_t)sku * 65536;
   L.total = o + 256;
   return L;
 }
 
-size_t fwd_f16x2_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r) { return make_layout(M, K, r).total; }
+size_t fwd_f16x2_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r) { return make_layout(M, K, r, N).total; }
 
 // power of two p with  v_max * p  in [2^13, 2^14)   (p = 1 for v_max == 0 or non-finite)
 __device__ __forceinline__ float pow2_scale_for(float vmax) {
@@ -234,6 +268,7 @@ __global__ __launch_bounds__(256) void prep_f16x2_kernel(PrepArgs a) {
 //   thi/tlo   = two fp16 limbs of t * 2^g[m];  rowinv[m] = 2^-g[m]
 // =================================================================================================
 struct XPassArgs {
+  int* zero_ptr; int zero_n;                // the streaming kernels' block 0 zeroes these ints (the contraction's split-K counters)
   const float* x; const float* sx; const float* zx; const float* aT;   // x [M,K]; aT = FQ(A)^T [r,K] fp32
   _Float16 *qx, *thi, *tlo; float* rowinv;
   int M, K, r, Kp, Rp;
@@ -245,7 +280,6 @@ struct XPassArgs {
   const float* xscale;                      // device {2^G, 2^-G}: power of two that puts the quantizer's range bound at 2^14
   float* t_out;                             // optional fp32 [M, r]: the LoRA-down product itself
   int lora_fq;                              // 1: the LoRA-down product consumes FQ(x) (part2 CPTLinear), 0: raw x (part1)
-  const float* ascale;                      // device {2^S, 2^-S} for the fp16 limbs of aT (xpass_panel16_kernel); null: f32 MFMA
   // optional LayerNorm prologue: x is the INPUT of the SwitchableLayerNorm in front of the layer
   // (switchable_batchnorm.py:102-109); the pass normalises each row on the fly -- weight * ((x - mean) / sqrt(var + eps)) + bias,
   // bit for bit what spq_layernorm writes -- so the normalised fp32 activation is never stored or re-read.  K <= 1024.
@@ -867,19 +901,8 @@ __global__ __launch_bounds__(512) void xpass_panel_kernel(XPassArgs a) {
   xpass_finish<2, 8>(a, acc, reinterpret_cast<float*>(xsm), m0, tid);
 }
 
-// -------------------------------------------------------------------------------------------------------------------
-// 16-row variant for small M (fewer than two 32-row blocks per CU): 16 rows x 8 chunks per panel (68 KB of LDS, 256 threads), so
-// two workgroups share a CU where the 32-row kernel leaves it one, and they cover each other's load phases and per-chunk
-// latency chains (the pass costs half as much per row once a CU holds two workgroups: 21 -> 10 us per 8192 x 768 rows).
-// LoRA-down on v_mfma_f32_16x16x4_f32: wave w owns k in [16w, 16w+16) of a chunk, lane quarter q its 4 contiguous k.
-// -------------------------------------------------------------------------------------------------------------------
-#ifndef SPQ_XP16R_CH
-#define SPQ_XP16R_CH 8
-#endif
-constexpr int XR16 = 16, XP16R_CH = SPQ_XP16R_CH;
-constexpr int XP16R_XS = XP16R_CH * XR16 * 256;             // 32 KB
-constexpr int XP16R_LDS = XP16R_XS + XP_NAS * XP_AS + 2 * XP16R_CH * 64 * 4 + 256;   // + 32 KB + 4 KB (+ LayerNorm row statistics)
-// finish of the 16-row kernels: sum the 4 per-wave k-partials (fixed order), per-row power-of-two scale, two fp16 limbs (+ t_out).
+constexpr int XR16 = 16;
+// finish of the streaming kernels (16 / 32 rows per workgroup): sum the 4 per-wave k-partials (fixed order), per-row power-of-two scale, two fp16 limbs (+ t_out).
 // red: [4][ROWS][64] floats (16 / 32 KB) of LDS that nothing else is using.
 template <int ROWS = XR16>          // ROWS = 32: waves 4..7 hold rows 16..31 (wave = 4 * row group + k-slice)
 __device__ __forceinline__ void xpass16_finish(const XPassArgs& a, const f32x4 (&acc)[4], float* red, int m0, int tid) {
@@ -921,145 +944,9 @@ __device__ __forceinline__ void xpass16_finish(const XPassArgs& a, const f32x4 (
   }
 }
 
-// PREP: every workgroup first makes `prep_rows` consecutive rows of the weight-side operands (prep_row_wave: FQ(W), fold sx,
-// FQ(B) column, exponent, limb split) -- the work of prep_f16x2_wave_kernel spread over the activation pass's workgroups, so
-// the per-call re-quantisation of the weights (lora.py:142, :50) costs no launch of its own and no extra round of workgroups.
 #ifndef SPQ_XP_DIAG    // tools/xpass_probe.py only (the library builds 0): 1 = no FQ(A)^T loads / LDS stores after the first chunk,
 #define SPQ_XP_DIAG 0  // 2 = no MFMAs, 4 = no level stores, 8 = no x copies after the first chunk, 16 = no per-chunk barrier
 #endif
-template <int PREP>   // 0: no weight rows; 1: fp16 limb rows; 2: int8 level rows (SPQ_PATH_I8)
-__global__ __launch_bounds__(256, SPQ_XP16R_CH <= 4 ? 3 : 2) void xpass_rows16_kernel(XPassArgs a, PrepArgs pa, int prep_rows) {
-  extern __shared__ __attribute__((aligned(16))) char xsm[];
-  constexpr int CH = XP16R_CH;
-  char* xs = xsm;
-  char* as = xsm + XP16R_XS;
-  float* sxs = reinterpret_cast<float*>(xsm + XP16R_XS + XP_NAS * XP_AS);
-  float* lnst = reinterpret_cast<float*>(xsm + XP16R_XS + XP_NAS * XP_AS + 2 * XP16R_CH * 64 * 4);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * XR16;
-  if (a.ln_w) ln_panel_stats(a, m0, XR16, lnst);            // visible to every thread after the first panel's barrier
-  const float qhi = (float)((1 << (a.bits - 1)) - 1), qlo = -qhi;
-  const float pscale = a.limbs ? a.xscale[0] : 1.f;
-  const bool with_lora = a.r > 0;
-  const int l15 = lane & 15, q4 = lane >> 4;
-  __shared__ float s_qn[256];
-  const float* qn_lut = (a.limbs || a.lora_fq) ? fill_log_qn_lut(s_qn, a.bits, a.qtype, a.symmetric) : nullptr;   // (uniform branch)
-
-  f32x4 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
-
-  // x copy: a 64-column chunk of the 16-row panel is 4 pieces of 1 KB (4 rows x 256 B); wave w issues piece w
-  const int prow = w * 4 + (lane >> 4), ppos = lane & 15;
-  const float* x_src = a.x + (int64_t)min(m0 + prow, a.M - 1) * a.K + ((ppos ^ (prow & 15)) << 2);
-  const int q_row = tid >> 4, q_pos = tid & 15;
-  const int q_kof = (q_pos ^ (q_row & 15)) << 2;
-  const int64_t q_dst = (int64_t)min(m0 + q_row, a.M - 1) * a.Kp + q_kof;
-
-  // FQ(A)^T chunk [64 j x 64 k] fp32: thread -> rows a_r, a_r+16, a_r+32, a_r+48, 16-B source chunk a_c; register staged
-  const int total_chunks = a.K / 64;
-  float4 ra[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int a_r = tid >> 4, a_c = tid & 15;
-  const float* a_src = a.aT + (int64_t)a_r * a.K + (a_c << 2);
-  const int64_t a_step = (int64_t)16 * a.K;
-  const int a_dst = a_r * 256 + ((a_c ^ (a_r & 15)) << 4);       // (a_r + 16 i) & 15 == a_r & 15
-#define SPQ_LOAD_A(k0)                                                                                       \
-  do {                                                                                                       \
-    ra[0] = *reinterpret_cast<const float4*>(a_src + (k0));                                                  \
-    ra[1] = *reinterpret_cast<const float4*>(a_src + a_step + (k0));                                         \
-    ra[2] = *reinterpret_cast<const float4*>(a_src + 2 * a_step + (k0));                                     \
-    ra[3] = *reinterpret_cast<const float4*>(a_src + 3 * a_step + (k0));                                     \
-  } while (0)
-#define SPQ_STORE_A(buf)                                                                                     \
-  do {                                                                                                       \
-    char* d_ = as + (buf) * XP_AS + a_dst;                                                                   \
-    *reinterpret_cast<float4*>(d_) = ra[0];                                                                  \
-    *reinterpret_cast<float4*>(d_ + 16 * 256) = ra[1];                                                       \
-    *reinterpret_cast<float4*>(d_ + 32 * 256) = ra[2];                                                       \
-    *reinterpret_cast<float4*>(d_ + 48 * 256) = ra[3];                                                       \
-  } while (0)
-
-  int gc = 0;
-  if (with_lora) SPQ_LOAD_A(0);
-  for (int p0 = 0; p0 < a.K; p0 += CH * 64) {
-    const int nch = min(CH, (a.K - p0) / 64);
-    for (int c = 0; c < nch; ++c)
-      if (!(SPQ_XP_DIAG & 8) || (p0 == 0 && c == 0)) glds16(x_src + p0 + c * 64, xs + c * (XR16 * 256) + w * 1024);
-    if (PREP && p0 == 0) {
-      // weight rows of this workgroup, while the first panel's copies are in flight (their latency and the rows' load latency
-      // overlap).  The rows' LoRA-B columns B[j][n0 .. n0+nrows) are short contiguous runs: staged [row][j] in LDS (the second
-      // FQ(A)^T buffer is not in use yet) instead of one strided scalar read per (row, j) from every wave.
-      const int n0 = (int)blockIdx.x * prep_rows;
-      const int np = (pa.N + GN - 1) / GN * GN;
-      const int nrows = min(prep_rows, np - n0);
-      const float* sbw = nullptr;
-      if (pa.B && nrows > 0) {
-        float* sB = reinterpret_cast<float*>(as + XP_AS);
-        const int nbv = min(nrows, pa.N - n0);
-        for (int e = threadIdx.x; e < pa.r * nbv; e += 256) {
-          const int j = e / nbv, i = e - j * nbv;
-          sB[i * pa.Rp + j] = pa.B[(int64_t)j * pa.N + n0 + i];
-        }
-        __syncthreads();
-        sbw = sB;
-      }
-      for (int i = (int)(threadIdx.x >> 6); i < nrows; i += 4)
-        prep_row_wave<(PREP == 1 ? 0 : 1), 4>(pa, n0 + i, threadIdx.x & 63, (sbw && n0 + i < pa.N) ? sbw + i * pa.Rp : nullptr);
-    }
-    for (int k = tid; k < nch * 64; k += 256) {
-      sxs[k] = a.x_pc ? a.sx[p0 + k] : a.sx[0];
-      sxs[CH * 64 + k] = (a.limbs || a.lora_fq) ? (a.x_pc ? a.zx[p0 + k] : a.zx[0]) : 0.f;
-    }
-    if (with_lora && p0 == 0) SPQ_STORE_A(0);
-    __syncthreads();                                       // vmcnt(0): the panel landed; FQ(A)^T chunk gc is in LDS
-    if (a.ln_w) { ln_panel_apply(a, xs, XR16 * 256, nch, p0, q_row, q_pos, q_kof, lnst); __syncthreads(); }
-    for (int c = 0; c < nch; ++c, ++gc) {
-      const int k0 = p0 + c * 64;
-      const bool next_a = with_lora && gc + 1 < total_chunks && !(SPQ_XP_DIAG & 1);
-      if (next_a) SPQ_LOAD_A((gc + 1) * 64);
-      if (!(SPQ_XP_DIAG & 4) || a.M == 12345) {
-        const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR16 * 256) + q_row * 256 + q_pos * 16);
-        const float4 sc = *reinterpret_cast<const float4*>(sxs + c * 64 + q_kof);
-        const float4 zp = *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + q_kof);
-        store_act4(a, q_dst + k0, v, sc, zp, qlo, qhi, pscale, qn_lut);
-      }
-      if (with_lora) {
-        const int pa = 4 * w + q4;                         // 16-B source chunk of this lane: k = 16 w + 4 q4 .. + 3
-        float4 av = *reinterpret_cast<const float4*>(xs + c * (XR16 * 256) + l15 * 256 + ((pa ^ l15) << 4));
-        if (a.lora_fq)
-          av = fq_act4(a, av, *reinterpret_cast<const float4*>(sxs + c * 64 + 4 * pa),
-                       *reinterpret_cast<const float4*>(sxs + CH * 64 + c * 64 + 4 * pa), qn_lut);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int rb = t * 16 + l15;
-          const float4 bv = *reinterpret_cast<const float4*>(as + (gc & 1) * XP_AS + rb * 256 + ((pa ^ (rb & 15)) << 4));
-          if (SPQ_XP_DIAG & 2) { acc[t][0] += av.x + bv.x; continue; }
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[t], 0, 0, 0);
-        }
-        if (next_a) SPQ_STORE_A((gc + 1) & 1);
-      }
-      if (!(SPQ_XP_DIAG & 16)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-    }
-    __syncthreads();
-  }
-#undef SPQ_LOAD_A
-#undef SPQ_STORE_A
-  if (!with_lora) return;
-  xpass16_finish(a, acc, reinterpret_cast<float*>(xsm), m0, tid);
-}
-
 // -------------------------------------------------------------------------------------------------------------------
 // Streaming form of the pass for the common case: symmetric min-max levels (fp16 / bytes), LoRA-down on the raw rows, no weight
 // rows.  The panel kernels above alternate "copy a panel" and "work on it", and their parts add up (measured with SPQ_XP_DIAG at
@@ -1141,7 +1028,8 @@ __device__ __forceinline__ void xpass_stream_body(const XPassArgs& a, char* xsm,
   const float pscale = (A8 == 3) ? a.xscale[0] : 1.f;
   __shared__ float s_qn[A8 == 3 ? 256 : 1];
   const float* qn_lut = (A8 == 3) ? fill_log_qn_lut(s_qn, a.bits, a.qtype, a.symmetric) : nullptr;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the scalar's load is out of the count
+  if (block == 0 && a.zero_ptr) for (int i = tid; i < a.zero_n; i += ROWS * 16) a.zero_ptr[i] = 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the scalar's load (and those stores) are out of the count
   issue(0, 0);
   if (nck > 1) issue(1, 1);
   if (LN) ln_panel_stats(a, m0, ROWS, lnst);                // its loads drain the count: chunks 0 and 1 land with them
@@ -1283,174 +1171,6 @@ __global__ __launch_bounds__(ROWS * 16, 2) void xpass_stream_prep_kernel(XPassAr
   prep_row_wave<MODE, 4>(pa, n0 + wv, threadIdx.x & 63, staged ? &sB[wv][0] : nullptr, d0, d1, v0, v1);
 }
 
-// -------------------------------------------------------------------------------------------------------------------
-// The same pass with the LoRA-down product on the f16 matrix pipe (fp32-input MFMA runs at 1/16 of its rate and was half of
-// this kernel's time at K = 3072).  x has no calibrated bound, so each 32-row panel gets per-row powers of two 2^g[m] from
-// its own row maxima (one LDS sweep), x * 2^g and FQ(A)^T * 2^S are split into two fp16 limbs on the fly (S from the LoRA-A
-// quantizer's range, a.ascale), three v_mfma_f32_32x32x16_f16 per k-step of 16 (hi.hi, hi.lo, lo.hi), and the panel's
-// partial product is folded into an fp32 running sum with 2^-g[m] 2^-S before the next panel re-scales.  Waves 0..3 own the
-// four k-steps of a 64-column chunk; all 8 waves do the level pass.
-// -------------------------------------------------------------------------------------------------------------------
-constexpr int XP16_LDS = XP_LDS + 256;                     // + per-row scales of the current panel
-__global__ __launch_bounds__(512) void xpass_panel16_kernel(XPassArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char xsm[];
-  char* xs = xsm;
-  char* as = xsm + XP_XS;
-  float* sxs = reinterpret_cast<float*>(xsm + XP_XS + XP_NAS * XP_AS);
-  float* rs = reinterpret_cast<float*>(xsm + XP_LDS);      // [32] 2^g[m], [32] 2^-g[m] * 2^-S
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * XR;
-  const float qhi = (float)((1 << (a.bits - 1)) - 1), qlo = -qhi;
-  const float pscale = a.limbs ? a.xscale[0] : 1.f;
-  const bool with_lora = a.r > 0;
-  const int l31 = lane & 31, h = lane >> 5;
-  const float a_mul = a.ascale[0], a_inv = a.ascale[1];
-
-  f32x16 acc[2], tsum[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { acc[i][e] = 0.f; tsum[i][e] = 0.f; }
-
-  const int prow = w * 4 + (lane >> 4), ppos = lane & 15;
-  const float* x_src = a.x + (int64_t)min(m0 + prow, a.M - 1) * a.K + ((ppos ^ (prow & 15)) << 2);
-  const int q_row = tid >> 4, q_pos = tid & 15;
-  const int q_kof = (q_pos ^ (q_row & 15)) << 2;
-  const int64_t q_dst = (int64_t)min(m0 + q_row, a.M - 1) * a.Kp + q_kof;
-
-  // FQ(A)^T chunk g lives in buffer g & 1 as two fp16 planes [64 j][64 k] (hi at +0, lo at +8 KB); the 16-B piece c of row
-  // j sits at position c ^ ((j >> 1) & 7).  Staged through registers as in xpass_panel_kernel, converted on the way.
-  const int total_chunks = a.K / 64;
-  // Two register sets: chunk n travels in set n & 1, loaded two iterations before it is written to LDS, so the L2 latency
-  // of the FQ(A)^T rows (~1 us, longer than one chunk's work) never sits on the per-chunk critical path.
-  // (named registers and a chunk loop unrolled by two: a run-time set index makes hipcc copy the sets around and wait for
-  // loads it has just issued)
-  float4 ra0_0, ra1_0, ra0_1, ra1_1;
-  ra0_0 = ra1_0 = ra0_1 = ra1_1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int a_r = tid >> 4, a_c = tid & 15;                // row (and row + 32), 4 k at 4 a_c
-  const float* a_src = a.aT + (int64_t)a_r * a.K + (a_c << 2);
-  const int64_t a_step = (int64_t)32 * a.K;
-  const int a_dst0 = a_r * 128 + ((((a_c >> 1) ^ ((a_r >> 1) & 7)) << 4) | ((a_c & 1) << 3));
-  const int a_dst1 = (a_r + 32) * 128 + ((((a_c >> 1) ^ (((a_r + 32) >> 1) & 7)) << 4) | ((a_c & 1) << 3));
-#define SPQ_STORE_A(buf, R0, R1)                                                                          \
-  do {                                                                                                    \
-    char* d_ = as + (buf) * XP_AS;                                                                        \
-    union { _Float16 hh[4]; uint2 u; } hi_, lo_;                                                          \
-    split2((R0).x * a_mul, hi_.hh[0], lo_.hh[0]); split2((R0).y * a_mul, hi_.hh[1], lo_.hh[1]);           \
-    split2((R0).z * a_mul, hi_.hh[2], lo_.hh[2]); split2((R0).w * a_mul, hi_.hh[3], lo_.hh[3]);           \
-    *reinterpret_cast<uint2*>(d_ + a_dst0) = hi_.u; *reinterpret_cast<uint2*>(d_ + 8192 + a_dst0) = lo_.u; \
-    split2((R1).x * a_mul, hi_.hh[0], lo_.hh[0]); split2((R1).y * a_mul, hi_.hh[1], lo_.hh[1]);           \
-    split2((R1).z * a_mul, hi_.hh[2], lo_.hh[2]); split2((R1).w * a_mul, hi_.hh[3], lo_.hh[3]);           \
-    *reinterpret_cast<uint2*>(d_ + a_dst1) = hi_.u; *reinterpret_cast<uint2*>(d_ + 8192 + a_dst1) = lo_.u; \
-  } while (0)
-#define SPQ_LOAD_A(n, R0, R1)                                                          \
-  do {                                                                                 \
-    if ((n) < total_chunks) {                                                          \
-      (R0) = *reinterpret_cast<const float4*>(a_src + (n) * 64);                       \
-      (R1) = *reinterpret_cast<const float4*>(a_src + a_step + (n) * 64);              \
-    }                                                                                  \
-  } while (0)
-
-  int gc = 0;
-  if (with_lora) {
-    SPQ_LOAD_A(0, ra0_0, ra1_0);
-    SPQ_LOAD_A(1, ra0_1, ra1_1);
-  }
-  for (int p0 = 0; p0 < a.K; p0 += XP_CHUNKS * 64) {
-    const int nch = min(XP_CHUNKS, (a.K - p0) / 64);
-    for (int c = 0; c < nch; ++c) glds16(x_src + p0 + c * 64, xs + c * (XR * 256) + w * 1024);
-    for (int k = tid; k < nch * 64; k += 512) {
-      sxs[k] = a.x_pc ? a.sx[p0 + k] : a.sx[0];
-      sxs[XP_CHUNKS * 64 + k] = (a.limbs || a.lora_fq) ? (a.x_pc ? a.zx[p0 + k] : a.zx[0]) : 0.f;
-    }
-    if (with_lora && p0 == 0) {
-      SPQ_STORE_A(0, ra0_0, ra1_0);
-      SPQ_LOAD_A(2, ra0_0, ra1_0);
-    }
-    __syncthreads();                                       // the panel landed; FQ(A)^T chunk gc is in LDS
-    if (with_lora) {                                       // per-row scale of this panel: 16 lanes per row sweep its chunks
-      float mx = 0.f;
-      for (int c = 0; c < nch; ++c) {
-        const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + q_row * 256 + q_pos * 16);
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 4, 64)); mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
-      if (q_pos == 0) { const float p = pow2_scale_for(mx); rs[q_row] = p; rs[32 + q_row] = (1.0f / p) * a_inv; }
-      __syncthreads();
-    }
-    // chunk gc reads FQ(A)^T from LDS buffer gc & 1; gc is even at every panel start (XP_CHUNKS is even)
-    auto chunk = [&](int c, auto par_tag) {
-      constexpr int PAR = decltype(par_tag)::value;
-
-      const int k0 = p0 + c * 64;
-      const bool next_a = with_lora && gc + 1 < total_chunks;
-      {
-        const float4 v = *reinterpret_cast<const float4*>(xs + c * (XR * 256) + q_row * 256 + q_pos * 16);
-        const float4 sc = *reinterpret_cast<const float4*>(sxs + c * 64 + q_kof);
-        const float4 zp = *reinterpret_cast<const float4*>(sxs + XP_CHUNKS * 64 + c * 64 + q_kof);
-        store_act4(a, q_dst + k0, v, sc, zp, qlo, qhi, pscale);
-      }
-      if (with_lora && w < 4) {                            // k-step w of this chunk: k = 16 w + 8 h .. + 7
-        const int s0 = 4 * w + 2 * h;
-        const char* xrow = xs + c * (XR * 256) + l31 * 256;
-        float4 x0 = *reinterpret_cast<const float4*>(xrow + ((s0 ^ (l31 & 15)) << 4));
-        float4 x1 = *reinterpret_cast<const float4*>(xrow + (((s0 + 1) ^ (l31 & 15)) << 4));
-        if (a.lora_fq) {
-          const float* scp = sxs + c * 64 + 16 * w + 8 * h;
-          x0 = fq_act4(a, x0, *reinterpret_cast<const float4*>(scp), *reinterpret_cast<const float4*>(scp + XP_CHUNKS * 64));
-          x1 = fq_act4(a, x1, *reinterpret_cast<const float4*>(scp + 4), *reinterpret_cast<const float4*>(scp + XP_CHUNKS * 64 + 4));
-        }
-        const float rsc = rs[l31];
-        union { _Float16 hh[8]; f16x8 v; } xh, xl;
-        split2(x0.x * rsc, xh.hh[0], xl.hh[0]); split2(x0.y * rsc, xh.hh[1], xl.hh[1]);
-        split2(x0.z * rsc, xh.hh[2], xl.hh[2]); split2(x0.w * rsc, xh.hh[3], xl.hh[3]);
-        split2(x1.x * rsc, xh.hh[4], xl.hh[4]); split2(x1.y * rsc, xh.hh[5], xl.hh[5]);
-        split2(x1.z * rsc, xh.hh[6], xl.hh[6]); split2(x1.w * rsc, xh.hh[7], xl.hh[7]);
-        const char* ab = as + PAR * XP_AS;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int j = t * 32 + l31;
-          const int off = j * 128 + (((2 * w + h) ^ ((j >> 1) & 7)) << 4);
-          const f16x8 bh = *reinterpret_cast<const f16x8*>(ab + off);
-          const f16x8 bl = *reinterpret_cast<const f16x8*>(ab + 8192 + off);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh.v, bh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh.v, bl, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl.v, bh, acc[t], 0, 0, 0);
-        }
-      }
-      if (next_a) {                                        // the other LDS buffer: every wave left it at the last barrier
-        if (PAR == 0) { SPQ_STORE_A(1, ra0_1, ra1_1); SPQ_LOAD_A(gc + 3, ra0_1, ra1_1); }
-        else { SPQ_STORE_A(0, ra0_0, ra1_0); SPQ_LOAD_A(gc + 3, ra0_0, ra1_0); }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-          ++gc;
-    };
-    {
-      int c = 0;
-      for (; c + 1 < nch; c += 2) { chunk(c, std::integral_constant<int, 0>{}); chunk(c + 1, std::integral_constant<int, 1>{}); }
-      if (c < nch) chunk(c, std::integral_constant<int, 0>{});
-    }
-    if (with_lora) {                                       // fold this panel's product into the fp32 sum: * 2^-g[m] 2^-S
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          tsum[t][e] += acc[t][e] * rs[32 + (e & 3) + 8 * (e >> 2) + 4 * h];
-          acc[t][e] = 0.f;
-        }
-    }
-    __syncthreads();                                       // panel images and scales are free for the next panel
-  }
-#undef SPQ_LOAD_A
-#undef SPQ_STORE_A
-  if (!with_lora) return;
-  xpass_finish<2, 8>(a, tsum, reinterpret_cast<float*>(xsm), m0, tid);
-}
-
 // =================================================================================================
 // The contraction.
 // =================================================================================================
@@ -1471,6 +1191,8 @@ struct GemmF16Args {
   _Float16* lv; const float* lv_scale; int lv_ld, lv_pc; float lv_qhi;
   // LV = 2: two fp16 limbs of FQ(v) * 2^G for any consumer quantizer (hi -> lv, lo -> lv_lo)
   _Float16* lv_lo; const float* lv_zero; const float* lv_xscale; int lv_qtype, lv_sym, lv_bits;
+  // split-K (gemm_f16x2_t128_kernel): `split` workgroups share a tile's k range; partial sums meet in sk_part, see the kernel
+  int split; int* sk_cnt; float* sk_part;
 };
 
 // ---- LDS: two 64-deep stage buffers (A 256x64 f16 = 32 KB, B hi/lo 128x64 f16 = 16 KB each) + a dedicated
@@ -1485,488 +1207,6 @@ constexpr int GEMM_THREADS = 512;                  // 8 waves = 4(M) x 2(N), 64x
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-// DIAG bit mask (tools/gemm_bench only; the library instantiates 0): 1 = no global->LDS copies after the first stage,
-// 2 = no MFMA / fragment reads, 4 = no epilogue stores, 8 = MFMAs on stale registers (no fragment reads),
-// 16 = clock stamps, 32 = double MFMA work, 64 = no barriers
-//
-// Structure.  Persistent: one workgroup per CU walks tiles p = blockIdx.x + i*gridDim.x; the sequence of 64-deep
-// stages S_0, S_1, ... runs straight through tile boundaries, stage S_i in buffer i&1.  Per stage:
-//     every wave issues its 8 copy pieces of S_{i+1} (global -> LDS, 16 B per lane) into the other buffer
-//     raw s_barrier (no counter wait)            <- measured on gfx950 (tools/overlap_probe): a wave streaming MFMAs
-//                                                   starves the other waves of its SIMD of issue slots, so a copy that
-//                                                   is not issued BEFORE the MFMA streams start is issued after them
-//     MFMAs of S_i; fragment reads of k16 block s+1 are issued ahead of the MFMAs of block s
-//     s_waitcnt vmcnt(0) + s_barrier             <- S_{i+1} has landed, buffer of S_i is free
-// After a tile's last stage the waves transpose their accumulators through private LDS slices and store whole
-// 128-B lines; those stores drain under the next tile's first stage.
-// LoRA stages come first in a tile: (thi x {Bhi,Blo}) then (tlo x {Bhi}) per 64-wide block of r, then the partial
-// sums are multiplied by 2^-g[m] and the base stages (qx x {Whi,Wlo}) accumulate on top.
-#define SPQ_SYNC() do { if (!(DIAG & 64)) __syncthreads(); } while (0)
-template <int DIAG>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_kernel(GemmF16Args g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 1, wn = w & 1;
-  const int l31 = lane & 31, h = lane >> 5;
-
-  const int nwg = g.tiles_m * g.tiles_n;
-  const int nl = (g.Rp / GK) * 2;           // LoRA stages per tile
-  const int T = nl + g.Kp / GK;             // stages per tile
-  const int gstride = (int)gridDim.x;
-
-  // XCD-aware tile order (speed only): positions of one XCD (p % 8, observed round-robin placement) map to a
-  // contiguous run of tiles that walks the tile grid in bands of 8 tile-rows, column by column, so the ~32 tiles an
-  // XCD has in flight form a compact patch (8 row panels x 4 column panels) that fits its 4 MB L2.
-  auto tile_of = [&](int p, int& bm, int& bn) {
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = p & 7;
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (p >> 3);
-    constexpr int GROUP_M = 8;
-    const int band = wgid / (GROUP_M * g.tiles_n);
-    const int band_rows = min(GROUP_M, g.tiles_m - band * GROUP_M);
-    const int in_band = wgid - band * GROUP_M * g.tiles_n;
-    bm = (band * GROUP_M + in_band % band_rows) * GM;
-    bn = (in_band / band_rows) * GN;
-  };
-
-  int p = blockIdx.x;
-  if (p >= nwg) return;
-  int bm, bn;
-  tile_of(p, bm, bn);
-  unsigned long long t0c = 0, t0r = 0;
-  if (DIAG & 16) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
-
-  // ---- copies.  A piece = 1 KB = 8 rows x 8 chunks of 16 B; lane -> (row = lane>>3, chunk position = lane&7); the
-  // source chunk is position ^ ((row>>1)&7).  Wave w owns A pieces 4w..4w+3 and pieces 2w, 2w+1 of each B limb.
-  const int prow = lane >> 3, pchunk = lane & 7;
-  int a_row[4], a_col[4], b_row[2], b_col[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { a_row[i] = (4 * w + i) * 8 + prow; a_col[i] = swz(a_row[i], pchunk) * 8; }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { b_row[i] = (2 * w + i) * 8 + prow; b_col[i] = swz(b_row[i], pchunk) * 8; }
-  auto issue = [&](int t, int tbm, int tbn, int buf) {
-    char* sb = smem + buf * STAGE_BYTES;
-    const _Float16 *A, *Bh, *Bl; int lda, ldb, k0; bool two;
-    if (t < nl) {
-      const int which = t & 1;
-      A = which ? g.tlo : g.thi; lda = g.Rp; Bh = g.Bhi; Bl = g.Blo; ldb = g.Rp; k0 = (t >> 1) * GK; two = !which;
-    } else {
-      A = g.qx; lda = g.Kp; Bh = g.Whi; Bl = g.Wlo; ldb = g.Kp; k0 = (t - nl) * GK; two = true;
-    }
-    const _Float16* Ab = A + (int64_t)tbm * lda + k0;          // wave-uniform base, 32-bit per-lane offsets
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(Ab + (a_row[i] * lda + a_col[i]), sb + (4 * w + i) * 1024);
-    const _Float16* Bhb = Bh + (int64_t)tbn * ldb + k0;
-    const _Float16* Blb = Bl + (int64_t)tbn * ldb + k0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int off = b_row[i] * ldb + b_col[i];
-      glds16(Bhb + off, sb + STAGE_A + (2 * w + i) * 1024);
-      if (two) glds16(Blb + off, sb + STAGE_A + STAGE_B + (2 * w + i) * 1024);
-    }
-  };
-
-  // ---- fragments: per-lane LDS byte offsets: row part + swizzled chunk of k16 block s (chunk 2s+h)
-  const int sx7 = (l31 >> 1) & 7;                          // == ((row >> 1) & 7) for every fragment row of this lane
-  const int fa_row = (wm * 64 + l31) * 128;                // + tm * 4096
-  const int fb_row = STAGE_A + (wn * 64 + l31) * 128;      // + tn * 4096 (+ STAGE_B for the lo limb)
-  int koff[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) koff[s] = ((2 * s + h) ^ sx7) * 16;
-
-  struct Frags { f16x8 a[2], bh[2], bl[2]; };
-  f32x16 acc[2][2];
-  auto load_frags = [&](Frags& f, const char* sb, int s, bool two) {
-    if (DIAG & 8) {
-      asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.bh[0]), "+v"(f.bh[1]), "+v"(f.bl[0]), "+v"(f.bl[1]));
-      return;
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f.a[t] = *reinterpret_cast<const f16x8*>(sb + fa_row + t * 4096 + koff[s]);
-      f.bh[t] = *reinterpret_cast<const f16x8*>(sb + fb_row + t * 4096 + koff[s]);
-      if (two) f.bl[t] = *reinterpret_cast<const f16x8*>(sb + fb_row + STAGE_B + t * 4096 + koff[s]);
-    }
-  };
-  auto mfma_block = [&](const Frags& f, bool two) {
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
-        if (two) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm], f.bl[tn], acc[tm][tn], 0, 0, 0);
-      }
-  };
-  // stage t of the current tile (buffer cur); first put the next stage (nt of tile nbm,nbn) in flight
-  auto stage = [&](int cur, bool two, bool have_next, int nt, int nbm, int nbn) {
-    if (have_next && !(DIAG & 1)) issue(nt, nbm, nbn, cur ^ 1);
-    if (!(DIAG & 64)) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // all copies issued; no counter wait
-    const char* sb = smem + cur * STAGE_BYTES;
-    Frags f0, f1;
-    if (DIAG & 8) { f0.a[0] = f0.a[1] = f0.bh[0] = f0.bh[1] = f0.bl[0] = f0.bl[1] = (f16x8)(_Float16)1.f; f1 = f0; }
-    if (!(DIAG & 2)) {
-      load_frags(f0, sb, 0, two);
-      load_frags(f1, sb, 1, two); mfma_block(f0, two);
-      load_frags(f0, sb, 2, two); mfma_block(f1, two);
-      load_frags(f1, sb, 3, two); mfma_block(f0, two);
-      mfma_block(f1, two);
-      if (DIAG & 32) { mfma_block(f0, two); mfma_block(f1, two); mfma_block(f0, two); mfma_block(f1, two); }
-    }
-    SPQ_SYNC();                                            // vmcnt(0): my pieces of the next stage landed; barrier: all did
-  };
-
-  issue(0, bm, bn, 0);
-  SPQ_SYNC();
-  int base = 0;                                          // buffer of the current tile's stage 0
-  while (true) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
-
-    const int pn = p + gstride;
-    const bool more = pn < nwg;
-    int nbm = 0, nbn = 0;
-    if (more) tile_of(pn, nbm, nbn);
-    // epilogue operands of this tile, fetched now so that nothing has to be waited for at the end
-    float4 ep_rs[2], ep_bv[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
-      ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
-      if (n < g.N) {
-        ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);
-        if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
-      }
-    }
-
-    // LoRA segment first, so that its per-row scale applies to it alone
-    for (int t = 0; t < nl; t += 2) {
-      stage((base + t) & 1, true, true, t + 1, bm, bn);
-      const bool last = (t + 2 == T);
-      stage((base + t + 1) & 1, false, !last || more, last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
-    }
-    if (nl > 0) {                                        // LoRA partial sums -> units of the base sum: * 2^-g[m]
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = bm + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const float ri = g.rowinv[m];
-          acc[tm][0][e] *= ri; acc[tm][1][e] *= ri;
-        }
-    }
-    for (int t = nl; t < T; ++t) {
-      const bool last = (t + 1 == T);
-      stage((base + t) & 1, true, !last || more, last ? 0 : t + 1, last ? nbm : bm, last ? nbn : bn);
-    }
-
-    // ---- epilogue: y = acc * 2^-e[n] + bias[n].  Each wave transposes 16 rows x 32 cols at a time through its
-    // private LDS slice (row stride 144 B) and stores 16 B per lane: 8 rows x 128 B per instruction, whole lines.
-    // Interior tiles take a branch-free path (a lane-divergent guard makes hipcc wait vmcnt(0) after every store).
-    {
-      char* eb = smem + 2 * STAGE_BYTES + w * EPI_WAVE;
-      const int c4 = (lane & 7) * 4;                     // 8 lanes x 16 B per 128-B row
-      const bool interior = (bm + GM <= g.M) && (bn + GN <= g.N);
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int n = bn + wn * 64 + tn * 32 + c4;
-        const bool n_ok = n < g.N;                       // N % 4 == 0 is required by the launcher
-        const float4 rs = ep_rs[tn], bv = ep_bv[tn];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            // C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); e>>3 selects rows 16*half..
-#pragma unroll
-            for (int e8 = 0; e8 < 8; ++e8) {
-              const int r16 = (e8 & 3) + 8 * (e8 >> 2) + 4 * h;
-              *reinterpret_cast<float*>(eb + r16 * 144 + l31 * 4) = acc[tm][tn][half * 8 + e8];
-            }
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-              const int r16 = it * 8 + (lane >> 3);
-              const float4 v = *reinterpret_cast<const float4*>(eb + r16 * 144 + c4 * 4);
-              const int m = bm + wm * 64 + tm * 32 + half * 16 + r16;
-              float4 o;
-              o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
-              float* dst = g.y + (int64_t)m * g.N + n;
-              if (DIAG & 4) { if (v.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }
-              else if (interior) *reinterpret_cast<float4*>(dst) = o;
-              else if (n_ok && m < g.M) *reinterpret_cast<float4*>(dst) = o;
-            }
-          }
-      }
-    }
-    if (!more) break;
-    base = (base + T) & 1;
-    p = pn; bm = nbm; bn = nbn;
-  }
-  if ((DIAG & 16) && tid == 0) {
-    g.dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
-    g.dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
-  }
-}
-#undef SPQ_SYNC
-
-// Same kernel on v_mfma_f32_16x16x32_f16 (16 accumulator tiles of 16x16 per wave instead of 4 of 32x32): equal FLOPs
-// per cycle, but the chip may hold a higher clock on this shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).
-#define SPQ_SYNC() do { if (!(DIAG & 64)) __syncthreads(); } while (0)
-// AL = activation limbs: 1 integer levels (SPQ_PATH_F16X2); 2 two limbs of FQ(x) * 2^G (SPQ_PATH_F16X3), the base segment
-// then alternates [hi limb x (Whi, Wlo)] and [lo limb x Whi] stages.  Compile-time, so that the F16X2 code is untouched.
-// EPI = 1: y = gelu(acc * scale + bias), the exact (erf) GELU of models_sp.py:107 fused into the store.
-template <int DIAG, int AL, int EPI = 0>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f16x2_s16_kernel(GemmF16Args g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 1, wn = w & 1;
-  const int l15 = lane & 15, q4 = lane >> 4;
-
-  const int nwg = g.tiles_m * g.tiles_n;
-  const int nl = (g.Rp / GK) * 2;           // LoRA stages per tile
-  const int T = nl + AL * (g.Kp / GK);      // stages per tile
-  const int gstride = (int)gridDim.x;
-  const bool vecN = (g.N & 3) == 0;        // 16-B aligned output rows (the usual case); otherwise scalar stores
-
-  // XCD-aware tile order (speed only): positions of one XCD (p % 8, observed round-robin placement) map to a
-  // contiguous run of tiles that walks the tile grid in bands of 8 tile-rows, column by column, so the ~32 tiles an
-  // XCD has in flight form a compact patch (8 row panels x 4 column panels) that fits its 4 MB L2.
-  auto tile_of = [&](int p, int& bm, int& bn) {
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = p & 7;
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (p >> 3);
-    constexpr int GROUP_M = 8;
-    const int band = wgid / (GROUP_M * g.tiles_n);
-    const int band_rows = min(GROUP_M, g.tiles_m - band * GROUP_M);
-    const int in_band = wgid - band * GROUP_M * g.tiles_n;
-    bm = (band * GROUP_M + in_band % band_rows) * GM;
-    bn = (in_band / band_rows) * GN;
-  };
-
-  const float lora_to_base = (AL == 2) ? g.xscale[0] : 1.f;   // LoRA partial sums carry 2^e[n]; base sums 2^(e[n]+G)
-  const float out_scale = (AL == 2) ? g.xscale[1] : 1.f;
-  int p = blockIdx.x;
-  if (p >= nwg) return;
-  int bm, bn;
-  tile_of(p, bm, bn);
-  unsigned long long t0c = 0, t0r = 0;
-  if (DIAG & 16) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
-
-  // ---- copies.  A piece = 1 KB = 8 rows x 8 chunks of 16 B; lane -> (row = lane>>3, chunk position = lane&7); the
-  // source chunk is position ^ ((row>>1)&7).  Wave w owns A pieces 4w..4w+3 and pieces 2w, 2w+1 of each B limb.
-  const int prow = lane >> 3, pchunk = lane & 7;
-  int a_row[4], a_col[4], b_row[2], b_col[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { a_row[i] = (4 * w + i) * 8 + prow; a_col[i] = swz(a_row[i], pchunk) * 8; }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { b_row[i] = (2 * w + i) * 8 + prow; b_col[i] = swz(b_row[i], pchunk) * 8; }
-  auto issue = [&](int t, int tbm, int tbn, int buf) {
-    char* sb = smem + buf * STAGE_BYTES;
-    const _Float16 *A, *Bh, *Bl; int lda, ldb, k0; bool two;
-    if (t < nl) {
-      const int which = t & 1;
-      A = which ? g.tlo : g.thi; lda = g.Rp; Bh = g.Bhi; Bl = g.Blo; ldb = g.Rp; k0 = (t >> 1) * GK; two = !which;
-    } else if (AL == 1) {
-      A = g.qx; lda = g.Kp; Bh = g.Whi; Bl = g.Wlo; ldb = g.Kp; k0 = (t - nl) * GK; two = true;
-    } else {
-      const int tb = t - nl, which = tb & 1;
-      A = which ? g.xl : g.qx; lda = g.Kp; Bh = g.Whi; Bl = g.Wlo; ldb = g.Kp; k0 = (tb >> 1) * GK; two = !which;
-    }
-    const _Float16* Ab = A + (int64_t)tbm * lda + k0;          // wave-uniform base, 32-bit per-lane offsets
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(Ab + (a_row[i] * lda + a_col[i]), sb + (4 * w + i) * 1024);
-    const _Float16* Bhb = Bh + (int64_t)tbn * ldb + k0;
-    const _Float16* Blb = Bl + (int64_t)tbn * ldb + k0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int off = b_row[i] * ldb + b_col[i];
-      glds16(Bhb + off, sb + STAGE_A + (2 * w + i) * 1024);
-      if (two) glds16(Blb + off, sb + STAGE_A + STAGE_B + (2 * w + i) * 1024);
-    }
-  };
-
-  // ---- fragments: per-lane LDS byte offsets: row part + swizzled chunk of k16 block s (chunk 2s+h)
-  const int sx7 = (l15 >> 1) & 7;                          // == ((row >> 1) & 7) for every fragment row of this lane
-  const int fa_row = (wm * 64 + l15) * 128;                // + tm * 2048 (16 rows)
-  const int fb_row = STAGE_A + (wn * 64 + l15) * 128;      // + tn * 2048 (+ STAGE_B for the lo limb)
-  int koff[2];                                             // k32 block s: lane quarter q4 reads chunk 4s + q4
-#pragma unroll
-  for (int s = 0; s < 2; ++s) koff[s] = ((4 * s + q4) ^ sx7) * 16;
-
-  struct Frags { f16x8 a[4], bh[4], bl[4]; };
-  f32x4 acc[4][4];
-  auto load_frags = [&](Frags& f, const char* sb, int s, bool two) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f.a[t] = *reinterpret_cast<const f16x8*>(sb + fa_row + t * 2048 + koff[s]);
-      f.bh[t] = *reinterpret_cast<const f16x8*>(sb + fb_row + t * 2048 + koff[s]);
-      if (two) f.bl[t] = *reinterpret_cast<const f16x8*>(sb + fb_row + STAGE_B + t * 2048 + koff[s]);
-    }
-  };
-  auto mfma_block = [&](const Frags& f, bool two) {
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[tm], f.bh[tn], acc[tm][tn], 0, 0, 0);
-        if (two) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[tm], f.bl[tn], acc[tm][tn], 0, 0, 0);
-      }
-  };
-  // stage t of the current tile (buffer cur); first put the next stage (nt of tile nbm,nbn) in flight
-  auto stage = [&](int cur, bool two, bool have_next, int nt, int nbm, int nbn) {
-    if (have_next && !(DIAG & 1)) issue(nt, nbm, nbn, cur ^ 1);
-    if (!(DIAG & 64)) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // all copies issued; no counter wait
-    const char* sb = smem + cur * STAGE_BYTES;
-    Frags f0, f1;
-    if (!(DIAG & 2)) {
-      load_frags(f0, sb, 0, two);
-      load_frags(f1, sb, 1, two); mfma_block(f0, two);
-      mfma_block(f1, two);
-    }
-    SPQ_SYNC();                                            // vmcnt(0): my pieces of the next stage landed; barrier: all did
-  };
-
-  issue(0, bm, bn, 0);
-  SPQ_SYNC();
-  int base = 0;                                          // buffer of the current tile's stage 0
-  while (true) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
-
-    const int pn = p + gstride;
-    const bool more = pn < nwg;
-    int nbm = 0, nbn = 0;
-    if (more) tile_of(pn, nbm, nbn);
-    // epilogue operands of this tile, fetched now so that nothing has to be waited for at the end
-    float4 ep_rs[2], ep_bv[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
-      ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
-      if (n < g.N) {
-        ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);            // rowscale has Np entries
-        if (AL == 2) { ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale; }   // exact
-        if (g.bias) {
-          if (vecN) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
-          else {                                                                 // N % 4 != 0: the last group is ragged
-            ep_bv[tn].x = g.bias[n];
-            if (n + 1 < g.N) ep_bv[tn].y = g.bias[n + 1];
-            if (n + 2 < g.N) ep_bv[tn].z = g.bias[n + 2];
-            if (n + 3 < g.N) ep_bv[tn].w = g.bias[n + 3];
-          }
-        }
-      }
-    }
-
-    // LoRA segment first, so that its per-row scale applies to it alone
-    for (int t = 0; t < nl; t += 2) {
-      stage((base + t) & 1, true, true, t + 1, bm, bn);
-      const bool last = (t + 2 == T);
-      stage((base + t + 1) & 1, false, !last || more, last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
-    }
-    if (nl > 0) {                                        // LoRA partial sums -> units of the base sum: * 2^-g[m]
-      f32x4 riv[4];                                        // the four loads first: one memory round trip, not four
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm) riv[tm] = *reinterpret_cast<const f32x4*>(g.rowinv + bm + wm * 64 + tm * 16 + 4 * q4);
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {                      // C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + e
-          float ri = riv[tm][e];
-          if (AL == 2) ri *= lora_to_base;
-#pragma unroll
-          for (int tn = 0; tn < 4; ++tn) acc[tm][tn][e] *= ri;
-        }
-    }
-    if (AL == 1) {
-      for (int t = nl; t < T; ++t) {
-        const bool last = (t + 1 == T);
-        stage((base + t) & 1, true, !last || more, last ? 0 : t + 1, last ? nbm : bm, last ? nbn : bn);
-      }
-    } else {
-      for (int t = nl; t < T; t += 2) {
-        stage((base + t) & 1, true, true, t + 1, bm, bn);
-        const bool last = (t + 2 == T);
-        stage((base + t + 1) & 1, false, !last || more, last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
-      }
-    }
-
-    // ---- epilogue: y = acc * 2^-e[n] + bias[n].  Each wave transposes 16 rows x 32 cols at a time through its
-    // private LDS slice (row stride 144 B) and stores 16 B per lane: 8 rows x 128 B per instruction, whole lines.
-    // Interior tiles take a branch-free path (a lane-divergent guard makes hipcc wait vmcnt(0) after every store).
-    {
-      char* eb = smem + 2 * STAGE_BYTES + w * EPI_WAVE;
-      const int c4 = (lane & 7) * 4;                     // 8 lanes x 16 B per 128-B row
-      const bool interior = vecN && (bm + GM <= g.M) && (bn + GN <= g.N);
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int n = bn + wn * 64 + tn * 32 + c4;
-        const bool n_ok = n < g.N;                       // N % 4 == 0 is required by the launcher
-        const float4 rs = ep_rs[tn], bv = ep_bv[tn];
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm) {
-            // 16 rows x 32 columns = the 16x16 tiles (tm, 2tn) and (tm, 2tn+1); col = lane&15, row = 4*(lane>>4) + e
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + l15 * 4) = acc[tm][2 * tn][e];
-              *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + (16 + l15) * 4) = acc[tm][2 * tn + 1][e];
-            }
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-              const int r16 = it * 8 + (lane >> 3);
-              const float4 v = *reinterpret_cast<const float4*>(eb + r16 * 144 + c4 * 4);
-              const int m = bm + wm * 64 + tm * 16 + r16;
-              float4 o;
-              o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
-              if (EPI == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
-              float* dst = g.y + (int64_t)m * g.N + n;
-              if (DIAG & 4) { if (v.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }
-              else if (interior) *reinterpret_cast<float4*>(dst) = o;
-              else if (n_ok && m < g.M) {
-                if (vecN) *reinterpret_cast<float4*>(dst) = o;
-                else {                                   // rows of y are not 16-B aligned: scalar stores, ragged tail
-                  dst[0] = o.x;
-                  if (n + 1 < g.N) dst[1] = o.y;
-                  if (n + 2 < g.N) dst[2] = o.z;
-                  if (n + 3 < g.N) dst[3] = o.w;
-                }
-              }
-            }
-          }
-      }
-    }
-    if (!more) break;
-    base = (base + T) & 1;
-    p = pn; bm = nbm; bn = nbn;
-  }
-  if ((DIAG & 16) && tid == 0) {
-    g.dbg[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
-    g.dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
-  }
-}
-#undef SPQ_SYNC
-
-// =================================================================================================
-// The contraction, byte-level variant (input quantizer <= 8 bit): the level matrix is stored as bytes q + 128, which
-// halves the A-side bytes of every stage (global -> LDS copies are what the matrix pipe waits for) and lets THREE
-// 48-KB stage buffers fit in LDS, so every copy has two full stages to land (counted vmcnt, raw barriers).
-// Bytes become exact fp16 in registers with two instructions per pair: v_perm_b32 builds fp16(1024 + u) (0x6400 | u),
-// v_pk_add_f16 subtracts 1152.
-//
-// Stage kinds per tile (all use the slot layout [A 16 KB][B-hi 16 KB][B-lo 16 KB]):
-//   LORA2 (32 deep)  A = thi block (fp16), B = {Bhi, Blo}      16 MFMAs per wave
-//   LORA1 (32 deep)  A = tlo block (fp16), B = {Bhi}            8 MFMAs per wave
-//   BASE  (64 deep)  A = level bytes,      B = {Whi, Wlo}      32 MFMAs per wave
-// k assignment inside a BASE stage: lane half h owns bytes [32h, 32h+32) of its row; MFMA s (0..3) covers
-// k = 32h + 8s .. +7 on both operands (any assignment is valid as long as A and B agree), so a lane reads its A operand
-// for two MFMAs with ONE 16-byte LDS read.
-// =================================================================================================
 // -------------------------------------------------------------------------------------------------------------------
 // 128 x 128 tiles, 4 waves (2 x 2 of 64 x 64), ONE 48 KB stage buffer: 57 KB of LDS, so two workgroups share a CU and cover
 // each other's copy latency, barriers, tile prologues and epilogues (inside one workgroup of gemm_f16x2_s16_kernel those
@@ -2022,7 +1262,7 @@ constexpr int T128_LDS = T128_DEFER ? T128_STAGE : T128_STAGE + 4 * EPI_WAVE;
 // LV = 1: the store also writes the next layer's level matrix (GemmF16Args::lv): q = clamp(rint(o / s[n]), +-qhi) of the very
 // value o it stores -- IEEE division, round half to even, as quantization_methods.py:14-15 -- four fp16 levels (8 B) per lane
 // next to (or, with g.y null, instead of) the 16 B of fp32.
-template <int AL, int EPI, int LV = 0>
+template <int AL, int EPI, int LV = 0, bool SK = false>   // SK: the split-K form (plain epilogue only: EPI = LV = 0)
 __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2046,10 +1286,34 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
   };
   const float lora_to_base = (AL == 2) ? g.xscale[0] : 1.f;
   const float out_scale = (AL == 2) ? g.xscale[1] : 1.f;
+  // Split-K (g.split = S > 1, chosen by the host when the tiles alone leave workgroup slots empty: N <= 1024 at M = 8192): unit
+  // p = h * nwg + tile accumulates the stages [bound(h), bound(h + 1)) of its tile; the LoRA stages and their rescale stay whole
+  // in h = 0.  The S partial sums are combined in FIXED order h = 0, 1, .. by whichever unit arrives last (below), so the result
+  // does not depend on the arrival order.
+  const int S = (SK && g.split > 1) ? g.split : 1;
+  const int units = nwg * S;
   int p = blockIdx.x;
-  if (p >= nwg) return;
+  if (p >= units) return;
+  int sk_h = 0, tile = p;
+  int t_lo = 0, t_hi = T;
+  auto unit_of = [&](int u) {
+    sk_h = u / nwg; tile = u - sk_h * nwg;
+    t_lo = 0; t_hi = T;
+    if (SK && S > 1) {
+      const int share = (T + S - 1) / S;
+      auto bound = [&](int h) {
+        if (h <= 0) return 0;
+        if (h >= S) return T;
+        int b = max(nl, h * share);
+        if (AL == 2) b = nl + ((b - nl + 1) & ~1);            // a two-limb stage and its one-limb stage stay together
+        return min(b, T);
+      };
+      t_lo = bound(sk_h); t_hi = bound(sk_h + 1);
+    }
+  };
+  unit_of(p);
   int bm, bn;
-  tile_of(p, bm, bn);
+  tile_of(tile, bm, bn);
 
   const int prow = lane >> 3, pchunk = lane & 7;
   int pc_row[4], pc_col[4];                                 // wave w owns pieces 4w..4w+3 of A and of each B limb
@@ -2120,7 +1384,7 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
 #if T128_PRIO == 6 || T128_PRIO == 7   // the three workgroups of a CU take the three priorities in turn, 1/T128_PRIO_DIV of their stages each
     {
       constexpr int DIV = T128_PRIO == 6 ? 3 : T128_PRIO_DIV;
-      const int per = max(1, (T * ((nwg + gstride - 1) / gstride) + DIV - 1) / DIV);
+      const int per = max(1, ((t_hi - t_lo) * ((units + gstride - 1) / gstride) + DIV - 1) / DIV);
       if (stage_ctr % per == 0) {
         const int pr = (prio_ctr + stage_ctr / per) % 3;
         if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(T128_PRIO_MID); else __builtin_amdgcn_s_setprio(T128_PRIO_HI);
@@ -2173,7 +1437,7 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
 #if T128_DIAG & 8
   const unsigned long long t_real = __builtin_amdgcn_s_memrealtime();
 #endif
-  issue(0, bm, bn);
+  if (t_lo < t_hi) issue(t_lo, bm, bn);
   while (true) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -2182,15 +1446,15 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[i][jj][e] = 0.f;
     const int pn = p + gstride;
-    const bool more = pn < nwg;
+    const bool more = !SK && pn < units;                // (split-K: one unit per workgroup, the host sizes the grid so)
     int nbm = 0, nbn = 0;
     if (more) tile_of(pn, nbm, nbn);
-    for (int t = 0; t < nl; t += 2) {
+    for (int t = t_lo; t < min(nl, t_hi); t += 2) {
       stage(true, true, t + 1, bm, bn);
-      const bool last = (t + 2 == T);
+      const bool last = (t + 2 == t_hi);
       stage(false, !last || (more && !T128_DEFER), last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
     }
-    if (nl > 0) {                                        // LoRA partial sums -> units of the base sum: * 2^-g[m]
+    if (nl > 0 && t_lo == 0) {                           // LoRA partial sums -> units of the base sum: * 2^-g[m]
       f32x4 riv[4];                                        // the four loads first: one memory round trip, not four
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm) riv[tm] = *reinterpret_cast<const f32x4*>(g.rowinv + bm + wm * 64 + tm * 16 + 4 * q4);
@@ -2205,16 +1469,70 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
         }
     }
     if (AL == 1) {
-      for (int t = nl; t < T; ++t) {
-        const bool last = (t + 1 == T);
+      for (int t = max(nl, t_lo); t < t_hi; ++t) {
+        const bool last = (t + 1 == t_hi);
         stage(true, !last || (more && !T128_DEFER), last ? 0 : t + 1, last ? nbm : bm, last ? nbn : bn);
       }
     } else {
-      for (int t = nl; t < T; t += 2) {
+      for (int t = max(nl, t_lo); t < t_hi; t += 2) {
         stage(true, true, t + 1, bm, bn);
-        const bool last = (t + 2 == T);
+        const bool last = (t + 2 == t_hi);
         stage(false, !last || (more && !T128_DEFER), last ? 0 : t + 2, last ? nbm : bm, last ? nbn : bn);
       }
+    }
+    if (SK && S > 1) {
+      // The tile's S units take a ticket each.  All but the last arrival store their accumulators (16 B per lane, the register
+      // image) to sk_part[tile][h] and leave.  The last arrival waits until S - 1 are done -- they are running or finished and none
+      // of them waits for anything, so the wait ends -- and sums h = 0 .. S - 1 in that order with its own registers in its own
+      // place: the sum is the same whoever came last.
+      // Coherence: every access to the partial sums carries sc1 (agent scope: performed at the point all XCDs share, like a
+      // relaxed agent-scope atomic), so no cache write-back / invalidate is needed -- an agent-scope release fence here
+      // (buffer_wbl2: write back the XCD's whole L2) in every wave of 768 workgroups cost 110 us at the attn c_proj shape.
+      // Order: stores, s_waitcnt vmcnt(0) in every wave, barrier, then the `done` counter; the reader polls `done`, barrier, loads.
+      int* cnt = g.sk_cnt + 2 * tile;                       // {tickets, done}; zeroed by the host side of this call
+      f32x4* part = reinterpret_cast<f32x4*>(g.sk_part) + (int64_t)tile * S * (16 * 256) + tid;
+      int* tk = reinterpret_cast<int*>(smem);               // (the stage buffer is free: the last stage ended with a barrier)
+      if (tid == 0) tk[0] = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int ticket = tk[0];
+      __syncthreads();                                      // (the epilogue writes its slices over tk)
+      if (ticket != S - 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(part + (sk_h * 16 + i) * 256), "v"(acc[i >> 2][i & 3]) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S - 1 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(4);
+      }
+      __syncthreads();
+      auto combine = [&](auto HALF) {                       // 8 accumulator blocks at a time: 32 registers of loads in flight
+        constexpr int half = decltype(HALF)::value;
+        f32x4 run[8];
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          if (h < S) {
+            f32x4 v[8];
+            if (sk_h != h) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(part + (h * 16 + half * 8 + i) * 256) : "memory");
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v[i] = acc[(half * 8 + i) >> 2][i & 3];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) run[i] = (h == 0) ? v[i] : run[i] + v[i];
+          }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[(half * 8 + i) >> 2][i & 3] = run[i];
+      };
+      combine(std::integral_constant<int, 0>{});
+      combine(std::integral_constant<int, 1>{});
     }
     // epilogue operands: fetched here, not at the tile's start (16 registers that three waves per SIMD do not leave through
     // the stage loop); the CU's other workgroups cover the load's latency
@@ -2237,15 +1555,24 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
         }
       }
       if (n < g.N) {
-        ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);
+        ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);     // [Np]: padded
         if (AL == 2) { ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale; }
-        if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
+        if (g.bias) {
+          if (LV != 0 || (g.N & 3) == 0) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
+          else {                                             // [N], ragged tail
+            ep_bv[tn].x = g.bias[n];
+            if (n + 1 < g.N) ep_bv[tn].y = g.bias[n + 1];
+            if (n + 2 < g.N) ep_bv[tn].z = g.bias[n + 2];
+            if (n + 3 < g.N) ep_bv[tn].w = g.bias[n + 3];
+          }
+        }
       }
     }
     {                                                        // epilogue
       char* eb = smem + (T128_DEFER ? 0 : T128_STAGE) + w * EPI_WAVE;     // T128_DEFER: inside the (now free) stage buffer
       const int c4 = (lane & 7) * 4;
-      const bool interior = (bm + 128 <= g.M) && (bn + GN <= g.N);
+      const bool vecN = LV != 0 || (g.N & 3) == 0;           // else rows of y are not 16-B aligned: scalar stores (LV: N % 64 == 0)
+      const bool interior = (bm + 128 <= g.M) && (bn + GN <= g.N) && vecN;
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
         const int n = bn + wn * 64 + tn * 32 + c4;
@@ -2291,7 +1618,15 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
             }
             if (T128_DIAG & 4) { if (o.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }   // (non-temporal stores: no change, 79.3 vs 79.2 us)
             else if (interior) *reinterpret_cast<float4*>(dst) = o;
-            else if (n_ok && m < g.M) *reinterpret_cast<float4*>(dst) = o;
+            else if (n_ok && m < g.M) {
+              if (vecN) *reinterpret_cast<float4*>(dst) = o;
+              else {
+                dst[0] = o.x;
+                if (n + 1 < g.N) dst[1] = o.y;
+                if (n + 2 < g.N) dst[2] = o.z;
+                if (n + 3 < g.N) dst[3] = o.w;
+              }
+            }
           }
         }
       }
@@ -2306,7 +1641,7 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
       __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
       issue(0, nbm, nbn);
     }
-    p = pn; bm = nbm; bn = nbn;
+    p = pn; bm = nbm; bn = nbn; tile = pn;
   }
 #if T128_DIAG & 8
   if (g.dbg && lane == 0) {
@@ -2320,309 +1655,6 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
 #endif
 }
 
-constexpr int U8_SLOT_A = GM * 64;                         // 16 KB (BASE: 256 x 64 B;  LORA: 256 x 32 fp16)
-constexpr int U8_SLOT_B = GN * 128;                        // 16 KB per limb (BASE: 128 x 64 fp16; LORA: 128 x 32 fp16 = 8 KB used)
-constexpr int U8_SLOT = U8_SLOT_A + 2 * U8_SLOT_B;         // 48 KB
-constexpr int U8_EPI_WAVE = 8 * 144;                       // 8 rows x (32 floats + pad) per wave
-constexpr int U8_LDS = 3 * U8_SLOT + 8 * U8_EPI_WAVE;      // 144 KB + 9 KB
-
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-// 16 level bytes -> two fp16x8 MFMA operands (bytes 0..7, bytes 8..15)
-__device__ __forceinline__ void unpack16(const uint4 raw, f16x8& lo8, f16x8& hi8) {
-  const unsigned d[4] = {raw.x, raw.y, raw.z, raw.w};
-  union { unsigned u[4]; f16x8 v; } o[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    union { unsigned u; f16x2 h; } a, b;
-    a.u = __builtin_amdgcn_perm(0x64646464u, d[i], 0x04010400u);      // [u0, 0x64, u1, 0x64] = fp16(1024+u0), fp16(1024+u1)
-    b.u = __builtin_amdgcn_perm(0x64646464u, d[i], 0x04030402u);      // u2, u3
-    a.h = a.h - (f16x2)(_Float16)1152.f;                               // exact: q = u - 128
-    b.h = b.h - (f16x2)(_Float16)1152.f;
-    o[i >> 1].u[2 * (i & 1)] = a.u;
-    o[i >> 1].u[2 * (i & 1) + 1] = b.u;
-  }
-  lo8 = o[0].v; hi8 = o[1].v;
-}
-
-struct GemmU8Args {
-  const unsigned char* qx;                  // [Mp, Kp] bytes q + 128
-  const _Float16 *thi, *tlo;                // [Mp, Rp]
-  const _Float16 *Whi, *Wlo, *Bhi, *Blo;    // [Np,Kp] x2, [Np,Rp] x2
-  const float *rowinv, *rowscale, *bias;
-  float* y;
-  int M, N, Kp, Rp;
-  int tiles_m, tiles_n;
-};
-
-// V (tools/gemm_bench only; the library instantiates 0): 1 = no byte unpack, 2 = no copies after the prologue,
-// 4 = extra barrier at stage start, 8 = no MFMAs / fragment reads, 16 = no epilogue stores
-template <int V>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_u8x2_kernel(GemmU8Args g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 1, wn = w & 1;
-  const int l31 = lane & 31, h = lane >> 5;
-
-  const int nwg = g.tiles_m * g.tiles_n;
-  const int nl = (g.Rp / 32) * 2;           // LoRA stages per tile (LORA2, LORA1 per 32-wide block of r)
-  const int T = nl + g.Kp / GK;             // stages per tile
-  const int gstride = (int)gridDim.x;
-
-  auto tile_of = [&](int p, int& bm, int& bn) {          // same XCD-aware band order as gemm_f16x2_kernel
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = p & 7;
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (p >> 3);
-    constexpr int GROUP_M = 8;
-    const int band = wgid / (GROUP_M * g.tiles_n);
-    const int band_rows = min(GROUP_M, g.tiles_m - band * GROUP_M);
-    const int in_band = wgid - band * GROUP_M * g.tiles_n;
-    bm = (band * GROUP_M + in_band % band_rows) * GM;
-    bn = (in_band / band_rows) * GN;
-  };
-
-  // ---- copies (1 KB pieces, lane*16 linear in LDS, swizzle applied to the per-lane source address)
-  // 64-B rows (A of every stage, B of LoRA stages): piece = 16 rows x 4 chunks, source chunk = pos ^ ((row>>2)&3)
-  // 128-B rows (B of BASE stages):                   piece =  8 rows x 8 chunks, source chunk = pos ^ ((row>>1)&7)
-  const int r64 = lane >> 2, p64 = lane & 3;
-  const int r128 = lane >> 3, p128 = lane & 7;
-  const int a_row0 = (2 * w) * 16 + r64, a_row1 = a_row0 + 16;          // A: 16 pieces, wave w owns 2w, 2w+1
-  const int a_c0 = (p64 ^ ((a_row0 >> 2) & 3)) * 16, a_c1 = (p64 ^ ((a_row1 >> 2) & 3)) * 16;     // byte offsets in the row
-  const int bb_row0 = (2 * w) * 8 + r128, bb_row1 = bb_row0 + 8;        // BASE B: 16 pieces per limb, wave w owns 2w, 2w+1
-  const int bb_c0 = (p128 ^ ((bb_row0 >> 1) & 7)) * 8, bb_c1 = (p128 ^ ((bb_row1 >> 1) & 7)) * 8; // fp16 element offsets
-  const int bl_row = w * 16 + r64;                                       // LoRA B: 8 pieces per limb, wave w owns piece w
-  const int bl_c = (p64 ^ ((bl_row >> 2) & 3)) * 8;
-
-  // The copies of a stage are planned once (per-lane source pointers, wave-uniform LDS destinations) and then issued
-  // one instruction at a time BETWEEN groups of MFMAs of the running stage: an LDS-DMA instruction occupies its wave's
-  // issue for tens of cycles, which the matrix pipe covers with the MFMAs already queued (and the SIMD's other wave).
-  const char* cp_src[6];
-  int cp_dst[6];
-  int cp_n = 0;
-  // per-lane source bases of the load cursor's tile (recomputed only when it enters a new tile)
-  const char *tb_a0, *tb_a1, *tb_w0h, *tb_w0l, *tb_w1h, *tb_w1l, *tb_t0h, *tb_t1h, *tb_t0l, *tb_t1l, *tb_bh, *tb_bl;
-  auto tile_bases = [&](int tbm, int tbn) {
-    const unsigned char* A = g.qx + (int64_t)tbm * g.Kp;
-    tb_a0 = reinterpret_cast<const char*>(A + (int64_t)a_row0 * g.Kp + a_c0);
-    tb_a1 = reinterpret_cast<const char*>(A + (int64_t)a_row1 * g.Kp + a_c1);
-    const int64_t b0 = (int64_t)tbn * g.Kp;
-    tb_w0h = reinterpret_cast<const char*>(g.Whi + b0 + (int64_t)bb_row0 * g.Kp + bb_c0);
-    tb_w0l = reinterpret_cast<const char*>(g.Wlo + b0 + (int64_t)bb_row0 * g.Kp + bb_c0);
-    tb_w1h = reinterpret_cast<const char*>(g.Whi + b0 + (int64_t)bb_row1 * g.Kp + bb_c1);
-    tb_w1l = reinterpret_cast<const char*>(g.Wlo + b0 + (int64_t)bb_row1 * g.Kp + bb_c1);
-    tb_t0h = reinterpret_cast<const char*>(g.thi + (int64_t)(tbm + a_row0) * g.Rp) + a_c0;
-    tb_t1h = reinterpret_cast<const char*>(g.thi + (int64_t)(tbm + a_row1) * g.Rp) + a_c1;
-    tb_t0l = reinterpret_cast<const char*>(g.tlo + (int64_t)(tbm + a_row0) * g.Rp) + a_c0;
-    tb_t1l = reinterpret_cast<const char*>(g.tlo + (int64_t)(tbm + a_row1) * g.Rp) + a_c1;
-    const int64_t bo = (int64_t)(tbn + bl_row) * g.Rp + bl_c;
-    tb_bh = reinterpret_cast<const char*>(g.Bhi + bo);
-    tb_bl = reinterpret_cast<const char*>(g.Blo + bo);
-  };
-  const int d_a0 = (2 * w) * 1024, d_a1 = d_a0 + 1024;
-  const int d_b0h = U8_SLOT_A + (2 * w) * 1024, d_b0l = d_b0h + U8_SLOT_B, d_b1h = d_b0h + 1024, d_b1l = d_b0l + 1024;
-  const int d_lh = U8_SLOT_A + w * 1024, d_ll = d_lh + U8_SLOT_B;
-  auto plan = [&](int t, int slot) {
-    const int sb = slot * U8_SLOT;
-    if (t < nl) {
-      const int off = (t >> 1) * 64;                       // 32 fp16 per LoRA block
-      cp_src[0] = ((t & 1) ? tb_t0l : tb_t0h) + off; cp_dst[0] = sb + d_a0;
-      cp_src[1] = ((t & 1) ? tb_t1l : tb_t1h) + off; cp_dst[1] = sb + d_a1;
-      cp_src[2] = tb_bh + off; cp_dst[2] = sb + d_lh;
-      cp_src[3] = tb_bl + off; cp_dst[3] = sb + d_ll;      // LORA1 ignores it; keeps the count uniform
-      cp_n = 4;
-      return;
-    }
-    const int ka = (t - nl) * GK, kb = ka * 2;             // byte offsets: 64 level bytes / 64 fp16 per stage
-    cp_src[0] = tb_a0 + ka; cp_dst[0] = sb + d_a0;
-    cp_src[1] = tb_a1 + ka; cp_dst[1] = sb + d_a1;
-    cp_src[2] = tb_w0h + kb; cp_dst[2] = sb + d_b0h;
-    cp_src[3] = tb_w0l + kb; cp_dst[3] = sb + d_b0l;
-    cp_src[4] = tb_w1h + kb; cp_dst[4] = sb + d_b1h;
-    cp_src[5] = tb_w1l + kb; cp_dst[5] = sb + d_b1l;
-    cp_n = 6;
-  };
-#define SPQ_PIECE(J) do { if ((J) < cp_n && !(V & 2)) glds16(cp_src[J], smem + cp_dst[J]); } while (0)
-
-  // ---- fragment addressing
-  const int s3 = (l31 >> 2) & 3, s7 = (l31 >> 1) & 7;     // swizzle keys of this lane's fragment rows
-  const int fa = (wm * 64 + l31) * 64;                     // A row (64-B rows); + tm * 2048
-  const int fb128 = U8_SLOT_A + (wn * 64 + l31) * 128;     // BASE B row; + tn * 4096 (+ U8_SLOT_B for lo)
-  const int fb64 = U8_SLOT_A + (wn * 64 + l31) * 64;       // LoRA B row; + tn * 2048
-
-  f32x16 acc[2][2];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
-  };
-  // four MFMAs on the (tm, tn) accumulators with one limb
-  auto mfma4 = [&](const f16x8 (&a)[2], const f16x8 (&b)[2]) {
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-  };
-  auto base_stage = [&](const char* sb) {
-#pragma unroll
-    for (int jh = 0; jh < 2; ++jh) {                       // two halves of 32 k (per lane half: 16 bytes of A)
-      f16x8 a[2][2], bh[2][2], bl[2][2];                   // [s within the half][tile]
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        // read through the fp16 vector type: hipcc puts s_waitcnt vmcnt(0) (draining the copies in flight) in front of
-        // an integer-typed LDS read that follows an LDS-DMA, but not in front of a half-typed one
-        const f16x8 rawh = *reinterpret_cast<const f16x8*>(sb + fa + t * 2048 + (((2 * h + jh) ^ s3) << 4));
-        if (V & 1) { a[0][t] = rawh; a[1][t] = rawh; } else unpack16(__builtin_bit_cast(uint4, rawh), a[0][t], a[1][t]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int c = ((4 * h + 2 * jh + i) ^ s7) << 4;
-          bh[i][t] = *reinterpret_cast<const f16x8*>(sb + fb128 + t * 4096 + c);
-          bl[i][t] = *reinterpret_cast<const f16x8*>(sb + fb128 + U8_SLOT_B + t * 4096 + c);
-        }
-      }
-      mfma4(a[0], bh[0]); if (jh == 0) SPQ_PIECE(0); else SPQ_PIECE(4);
-      mfma4(a[0], bl[0]); if (jh == 0) SPQ_PIECE(1); else SPQ_PIECE(5);
-      mfma4(a[1], bh[1]); if (jh == 0) SPQ_PIECE(2);
-      mfma4(a[1], bl[1]); if (jh == 0) SPQ_PIECE(3);
-    }
-  };
-  auto lora_stage = [&](const char* sb, bool two) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {                          // two k16 blocks; standard k = 16s + 8h
-      f16x8 a[2], bh[2], bl[2];
-      const int c = ((2 * s + h) ^ s3) << 4;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        a[t] = *reinterpret_cast<const f16x8*>(sb + fa + t * 2048 + c);
-        bh[t] = *reinterpret_cast<const f16x8*>(sb + fb64 + t * 2048 + c);
-        if (two) bl[t] = *reinterpret_cast<const f16x8*>(sb + fb64 + U8_SLOT_B + t * 2048 + c);
-      }
-      mfma4(a, bh); if (s == 0) SPQ_PIECE(0); else SPQ_PIECE(3);
-      if (s == 0) SPQ_PIECE(1);
-      if (two) mfma4(a, bl);
-      if (s == 0) SPQ_PIECE(2); else { SPQ_PIECE(4); SPQ_PIECE(5); }
-    }
-  };
-
-  // cursors: compute (cp, ct, cbm, cbn); load (lp, lt, lbm, lbn) runs two stages ahead
-  int cp = blockIdx.x, cbm, cbn;
-  if (cp >= nwg) return;
-  tile_of(cp, cbm, cbn);
-  int lp = cp, lt = 0, lbm = cbm, lbn = cbn;
-  bool lvalid = true;
-  auto advance_load = [&]() {
-    if (++lt == T) {
-      lt = 0; lp += gstride;
-      lvalid = lp < nwg;
-      if (lvalid) { tile_of(lp, lbm, lbn); tile_bases(lbm, lbn); }
-    }
-  };
-  tile_bases(lbm, lbn);
-  // prologue: S_0, S_1 in flight, S_0 complete
-  plan(lt, 0); advance_load();
-#pragma unroll
-  for (int jj = 0; jj < 6; ++jj) if (jj < cp_n) glds16(cp_src[jj], smem + cp_dst[jj]);
-  int n1 = 0;
-  if (lvalid) {
-    plan(lt, 1); advance_load(); n1 = cp_n;
-#pragma unroll
-    for (int jj = 0; jj < 6; ++jj) if (jj < cp_n) glds16(cp_src[jj], smem + cp_dst[jj]);
-  }
-  if (n1 == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (n1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  zero_acc();
-
-  // The stage sequence is written as structured loops (LoRA pairs, then base stages, then the epilogue) so that the
-  // 64 accumulator registers flow straight through: a single `while` over a stage cursor makes hipcc shuffle all of
-  // them with v_mov at every iteration (measured: ~0.4 us per stage).
-  int slot = 0;
-  auto pre = [&]() -> int {                                // put S_{i+2} on the plan; returns its copy count
-    cp_n = 0;
-    if (lvalid) { plan(lt, slot == 0 ? 2 : slot - 1); advance_load(); }
-    if (V & 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-    return (V & 2) ? 0 : cp_n;
-  };
-  auto post = [&](int n2, bool more) {                     // S_{i+1} complete: only S_{i+2}'s copies may be outstanding
-    if (n2 == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (n2 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (more) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-    slot = slot == 2 ? 0 : slot + 1;
-  };
-  auto drain_pieces = [&]() { SPQ_PIECE(0); SPQ_PIECE(1); SPQ_PIECE(2); SPQ_PIECE(3); SPQ_PIECE(4); SPQ_PIECE(5); };
-
-#pragma unroll 1
-  while (true) {
-    const bool more_tiles = cp + gstride < nwg;
-    for (int t = 0; t < nl; t += 2) {
-      int n2 = pre();
-      if (!(V & 8)) lora_stage(smem + slot * U8_SLOT, true); else drain_pieces();
-      post(n2, true);
-      n2 = pre();
-      if (!(V & 8)) lora_stage(smem + slot * U8_SLOT, false); else drain_pieces();
-      post(n2, t + 2 < T || more_tiles);
-    }
-    if (nl > 0) {                                          // LoRA partial sums -> units of the base sum: * 2^-g[m]
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = cbm + wm * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const float ri = g.rowinv[m];
-          acc[tm][0][e] *= ri; acc[tm][1][e] *= ri;
-        }
-    }
-    for (int t = nl; t < T; ++t) {
-      const int n2 = pre();
-      if (!(V & 8)) base_stage(smem + slot * U8_SLOT); else drain_pieces();
-      post(n2, t + 1 < T || more_tiles);
-    }
-    {
-      // ---- epilogue: y = acc * 2^-e[n] + bias[n]; 8 rows x 32 cols at a time through a private LDS slice, 16-B stores
-      char* eb = smem + 3 * U8_SLOT + w * U8_EPI_WAVE;
-      const int c4 = (lane & 7) * 4, r8 = lane >> 3;
-      const bool interior = (cbm + GM <= g.M) && (cbn + GN <= g.N);
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int n = cbn + wn * 64 + tn * 32 + c4;
-        const bool n_ok = n < g.N;
-        float4 rs = make_float4(0.f, 0.f, 0.f, 0.f), bv = rs;
-        if (n_ok) {
-          rs = *reinterpret_cast<const float4*>(g.rowscale + n);
-          if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + n);
-        }
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {                    // rows 8q .. 8q+7 of the 32x32 tile: registers 4q..4q+3
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4)
-              *reinterpret_cast<float*>(eb + (e4 + 4 * h) * 144 + l31 * 4) = acc[tm][tn][4 * q + e4];
-            const float4 v = *reinterpret_cast<const float4*>(eb + r8 * 144 + c4 * 4);
-            const int m = cbm + wm * 64 + tm * 32 + 8 * q + r8;
-            float4 o;
-            o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
-            float* dst = g.y + (int64_t)m * g.N + n;
-            if (V & 16) { if (v.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }
-            else if (interior) *reinterpret_cast<float4*>(dst) = o;
-            else if (n_ok && m < g.M) *reinterpret_cast<float4*>(dst) = o;
-          }
-      }
-    }
-    if (!more_tiles) break;
-    zero_acc();
-    cp += gstride;
-    tile_of(cp, cbm, cbn);
-  }
-}
-
-#undef SPQ_PIECE
 // =================================================================================================
 // part2 CPTLinear (cpt_model.py:96-113): the LoRA branch consumes FQ(x) like the base term, so the layer is one contraction
 // against  W_eff = FQ(W) + s FQ(B) FQ(A)^T.  Two small kernels build it; the limb split is the ordinary row kernel.
@@ -2781,6 +1813,24 @@ extern "C" int spq_debug_xp_stamps(unsigned long long* host_out, int n) {
 }
 #endif
 
+// Tuning / A-B switches, read from the environment ONCE (first call) -- nothing on the per-call path calls getenv.
+// spq_debug_reload_switches() re-reads them (tests flip a switch inside one process, tests/test_gpu_xpass_stream.py).
+//   SPQ_XPASS_STREAM        0: the panel kernel instead of the streaming activation pass; 16 / 32: forced rows per workgroup
+//   SPQ_XPASS_STREAM_LIMBS  0: the limb form (F16X3 operand) stays on the panel kernel
+//   SPQ_PREP_ROLE           0: the weight rows as a launch of their own instead of extra workgroups of the activation launch
+//   SPQ_SPLIT_K             0: never split a tile's k range over several workgroups; 2..4: that many where legal; 1 / unset: by estimate
+struct Switches { int stream, stream_limbs, prep_role, split_k; };
+static Switches read_switches() {
+  Switches w;
+  const char* e = getenv("SPQ_XPASS_STREAM");        w.stream = e ? atoi(e) : 1;
+  e = getenv("SPQ_XPASS_STREAM_LIMBS");              w.stream_limbs = !(e && e[0] == '0');
+  e = getenv("SPQ_PREP_ROLE");                       w.prep_role = !(e && e[0] == '0');
+  e = getenv("SPQ_SPLIT_K");                         w.split_k = e ? atoi(e) : 1;
+  return w;
+}
+static Switches g_switches = read_switches();
+extern "C" int spq_debug_reload_switches(void) { g_switches = read_switches(); return SPQ_OK; }
+
 int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   const bool x3 = a->path == SPQ_PATH_F16X3;
   const int i8nl = i8_limbs_of(a->path);
@@ -2807,7 +1857,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     return SPQ_ERR_UNSUPPORTED;
   }
   SPQ_REQUIRE(a->w_rowscale, "spq_linear_lora_fwd: w_rowscale missing for SPQ_PATH_F16X2");
-  const F16x2Layout L = make_layout(a->M, a->K, a->r);
+  const F16x2Layout L = make_layout(a->M, a->K, a->r, a->N);
   const PrepLayout P = make_prep_layout(a->N, a->K, a->r);
   char* ws = (char*)a->workspace;
   const char* wp = (const char*)a->w_prep;
@@ -2825,17 +1875,18 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   x.xl = (_Float16*)(ws + L.off_xl); x.xscale = a->x_limb_scale;
   x.t_out = (a->r > 0) ? a->t_out : nullptr;
   x.lora_fq = (a->lora_on_fq_input && a->quantize_input) ? 1 : 0;
-  x.ascale = a->a_limb_scale;
   x.ln_w = a->ln_weight; x.ln_b = a->ln_bias; x.ln_eps = a->ln_eps;
   const bool lora_up = a->r > 0 && a->b_prep != nullptr;     // r > 0 without b_prep: LoRA-down only (t_out)
-  if (a->path == SPQ_PATH_U8X2 && a->bits > 8) {
-    set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 needs an input quantizer of at most 8 bits (got %d)", a->bits);
+  if (a->path == SPQ_PATH_U8X2) {
+    set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 (byte-level ring kernel) was measured slower than SPQ_PATH_F16X2 and is no longer in the library "
+              "(tools/variants/gemm_u8x2.h); use SPQ_PATH_F16X2 -- same prepared operands, same result");
     return SPQ_ERR_UNSUPPORTED;
   }
-  if (a->path == SPQ_PATH_U8X2 && (a->N & 3) != 0) { set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 needs N %% 4 == 0"); return SPQ_ERR_UNSUPPORTED; }
-  if (a->path == SPQ_PATH_U8X2 && a->epilogue != SPQ_EPILOGUE_NONE) { set_error("spq_linear_lora_fwd: SPQ_PATH_U8X2 has no fused epilogue"); return SPQ_ERR_UNSUPPORTED; }
-  const bool a8 = a->path == SPQ_PATH_U8X2;   // levels as bytes + 3-slot ring kernel (opt-in)
-  x.a8 = i8nl ? 2 : (a8 ? 1 : 0);
+  if (a->a_limb_scale) {
+    set_error("spq_linear_lora_fwd: a_limb_scale (LoRA-down on the f16 pipe, tools/variants/xpass_panel16.h) is no longer in the library; pass null");
+    return SPQ_ERR_UNSUPPORTED;
+  }
+  x.a8 = i8nl ? 2 : 0;
   const unsigned xgrid = (unsigned)((a->M + XR - 1) / XR);
   const bool panel_ok = (a->K % 64 == 0) && L.Rp <= 64 && aligned16(a->x) && (a->r == 0 || aligned16(a->a_prep)) && aligned16(x.sx) &&
                         aligned16(x.zx);
@@ -2845,40 +1896,30 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   // launch of a few dozen workgroups; SPQ_PREP_ROLE=0 turns that off); otherwise the ordinary preparation launch is issued first
   // (SPQ_PREP_INPASS=1: the earlier variant that spreads the rows over the 16-row activation kernel's own workgroups).
   PrepArgs pa;
-  int prep_rows = 0, at_blocks = 0;
-  static int rows16 = -1;
-  if (rows16 < 0) {
-    const char* e = getenv("SPQ_XPASS_ROWS16");
-    rows16 = (e && e[0] == '0') ? 0 : 1;
+  int at_blocks = 0;
+  const Switches sw = g_switches;
+  // split-K of the contraction (f16 limb kernels): decided here because the activation launch zeroes its counters
+  int sk = 1;
+  const int64_t sk_nwg = (L.Mp / 128) * (P.Np / GN);
+  if (!i8nl && do_gemm && a->epilogue == SPQ_EPILOGUE_NONE && !a->out_levels) {
+    const int nl = lora_up ? (int)(L.Rp / GK) * 2 : 0;
+    const int T = nl + (x3 ? 2 : 1) * (int)(L.Kp / GK);
+    sk = t128_split(sk_nwg, T, nl, (int64_t)T128_WGS * gemm_grid(1 << 30), sw.split_k);
+    if (sk > 1 && sk_nwg * sk > sk_reserve_units(a->M, a->N)) sk = 1;
   }
-  const char* ip = getenv("SPQ_PREP_INPASS");               // 1: the earlier in-pass variant (row work spread over the 16-row
-  const int fuse_prep = (ip && ip[0] == '1') ? 1 : 0;       // activation kernel's workgroups; measured slower, kept for the A/B)
-  const bool use_rows16 = panel_ok && !(x.ascale && a->r > 0) && rows16 && xgrid < 2 * gemm_grid(1 << 30);
-  const char* xs_env = getenv("SPQ_XPASS_STREAM");        // 0: the panel kernels, 1 / unset: auto, 16 / 32: forced row count (tuning, tests)
-  const int stream16 = xs_env ? atoi(xs_env) : 1;
-  // (the limb form of the streaming kernel has no LayerNorm prologue; SPQ_XPASS_STREAM_LIMBS=0 keeps limbs on the panel kernels)
-  const char* sl_env = getenv("SPQ_XPASS_STREAM_LIMBS");
-  const bool stream_limbs = !(sl_env && sl_env[0] == '0');
-  const bool stream_ok = panel_ok && stream16 && a->r > 0 && (!x.limbs || (stream_limbs && !a->ln_weight && a->quantize_input)) && !x.lora_fq && !x.ascale;
-  const char* re = getenv("SPQ_PREP_ROLE");                // read per call (tests flip it)
-  const int role_env = (re && re[0] == '0') ? 0 : 1;
+  bool sk_zeroed = false;
+  x.zero_ptr = nullptr; x.zero_n = 0;
+  const int stream16 = sw.stream;
+  // (the limb form of the streaming kernel has no LayerNorm prologue)
+  const bool stream_ok = panel_ok && stream16 && a->r > 0 && (!x.limbs || (sw.stream_limbs && !a->ln_weight && a->quantize_input)) && !x.lora_fq;
   bool role_prep = false;                                  // the row work as extra workgroups of the streaming activation launch
   if (a->prepare && do_xpass) {
     bool wave_ok = false;
     int prc = prepare_fill(a->prepare, pa, at_blocks, wave_ok);
     if (prc) return prc;
     if (a->prepare->N != a->N || a->prepare->K != a->K || a->prepare->r < a->r) { set_error("spq_linear_lora_fwd: prepare args describe another layer"); return SPQ_ERR_INVALID; }
-    const int64_t xb = (a->M + XR16 - 1) / XR16;
-    const int64_t rows_each = (pad_to(a->N, GN) + xb - 1) / xb;
-    if (role_env && stream_ok && !a->ln_weight && wave_ok && a->K <= 1024) {
+    if (sw.prep_role && stream_ok && !a->ln_weight && wave_ok && a->K <= 1024) {
       role_prep = true;
-      if (at_blocks) {
-        fq_transpose_kernel<<<(unsigned)at_blocks, 256, 0, st>>>(pa);
-        prc = check_launch("spq_linear_lora_fwd(FQ(A)^T)");
-        if (prc) return prc;
-      }
-    } else if (fuse_prep && use_rows16 && wave_ok && rows_each <= 8 && a->K <= 1024) {   // the in-pass row code covers K <= 1024
-      prep_rows = (int)rows_each;
       if (at_blocks) {
         fq_transpose_kernel<<<(unsigned)at_blocks, 256, 0, st>>>(pa);
         prc = check_launch("spq_linear_lora_fwd(FQ(A)^T)");
@@ -2894,7 +1935,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   }
   if (a->ln_weight && do_xpass) {
     // the LayerNorm prologue lives in the panel kernels (fp32-MFMA LoRA-down), rows of at most 1024 elements
-    if (!a->ln_bias || !panel_ok || a->K > 1024 || (x.ascale && a->r > 0) || !aligned16(a->ln_weight) || !aligned16(a->ln_bias)) {
+    if (!a->ln_bias || !panel_ok || a->K > 1024 || !aligned16(a->ln_weight) || !aligned16(a->ln_bias)) {
       set_error("spq_linear_lora_fwd: the LayerNorm prologue needs K %% 64 == 0, K <= 1024, rank <= 64 and 16-byte aligned operands");
       return SPQ_ERR_UNSUPPORTED;
     }
@@ -2906,19 +1947,13 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
       hipError_t e = hipFuncSetAttribute((const void*)xpass_panel_kernel<XP_CHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, XP_LDS);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(xpass LDS %d B): %s", XP_LDS, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
       (void)hipFuncSetAttribute((const void*)xpass_panel_kernel<XP_CHUNKS_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, xp_lds(XP_CHUNKS_SMALL));
-      (void)hipFuncSetAttribute((const void*)xpass_panel16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XP16_LDS);
-      (void)hipFuncSetAttribute((const void*)xpass_rows16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, XP16R_LDS);
-      (void)hipFuncSetAttribute((const void*)xpass_rows16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, XP16R_LDS);
-      (void)hipFuncSetAttribute((const void*)xpass_rows16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, XP16R_LDS);
     }
-    const bool use_stream = stream_ok && prep_rows == 0;
-    if (use_stream) {
+    if (stream_ok) {
+      if (sk > 1) { x.zero_ptr = (int*)(ws + L.off_skcnt); x.zero_n = (int)(2 * sk_nwg); sk_zeroed = true; }
       if (AttrOnce once(7); once.first) {
 #define SPQ_XS_ATTR(R, A8, LN) (void)hipFuncSetAttribute((const void*)xpass_stream_kernel<R, A8, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, xs_lds(R))
-        SPQ_XS_ATTR(16, 0, false); SPQ_XS_ATTR(16, 1, false); SPQ_XS_ATTR(16, 2, false);
-        SPQ_XS_ATTR(16, 0, true); SPQ_XS_ATTR(16, 1, true); SPQ_XS_ATTR(16, 2, true);
-        SPQ_XS_ATTR(32, 0, false); SPQ_XS_ATTR(32, 1, false); SPQ_XS_ATTR(32, 2, false);
-        SPQ_XS_ATTR(32, 0, true); SPQ_XS_ATTR(32, 1, true); SPQ_XS_ATTR(32, 2, true);
+        SPQ_XS_ATTR(16, 0, false); SPQ_XS_ATTR(16, 2, false); SPQ_XS_ATTR(16, 0, true); SPQ_XS_ATTR(16, 2, true);
+        SPQ_XS_ATTR(32, 0, false); SPQ_XS_ATTR(32, 2, false); SPQ_XS_ATTR(32, 0, true); SPQ_XS_ATTR(32, 2, true);
         SPQ_XS_ATTR(16, 3, false); SPQ_XS_ATTR(32, 3, false);
 #undef SPQ_XS_ATTR
       }
@@ -2928,8 +1963,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
       if (role_prep) {
         if (AttrOnce once(8); once.first) {
 #define SPQ_XSP_ATTR(R, A8, MODE) (void)hipFuncSetAttribute((const void*)xpass_stream_prep_kernel<R, A8, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, xs_lds(R))
-          SPQ_XSP_ATTR(16, 0, 0); SPQ_XSP_ATTR(16, 1, 0); SPQ_XSP_ATTR(16, 2, 1); SPQ_XSP_ATTR(32, 0, 0); SPQ_XSP_ATTR(32, 1, 0); SPQ_XSP_ATTR(32, 2, 1);
-          SPQ_XSP_ATTR(16, 3, 0); SPQ_XSP_ATTR(32, 3, 0);
+          SPQ_XSP_ATTR(16, 0, 0); SPQ_XSP_ATTR(16, 2, 1); SPQ_XSP_ATTR(32, 0, 0); SPQ_XSP_ATTR(32, 2, 1); SPQ_XSP_ATTR(16, 3, 0); SPQ_XSP_ATTR(32, 3, 0);
 #undef SPQ_XSP_ATTR
         }
         const int R = r32 ? 32 : 16;
@@ -2937,25 +1971,19 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
         const unsigned nrow = (unsigned)((pad_to(a->N, GN) + R / 4 - 1) / (R / 4));
 #define SPQ_XSP_LAUNCH(R, A8, MODE) xpass_stream_prep_kernel<R, A8, MODE><<<nx + nrow, R * 16, xs_lds(R), st>>>(x, pa, (int)nx)
         if (x.limbs) { if (r32) SPQ_XSP_LAUNCH(32, 3, 0); else SPQ_XSP_LAUNCH(16, 3, 0); }
-        else if (r32) { if (x.a8 == 0) SPQ_XSP_LAUNCH(32, 0, 0); else if (x.a8 == 1) SPQ_XSP_LAUNCH(32, 1, 0); else SPQ_XSP_LAUNCH(32, 2, 1); }
-        else { if (x.a8 == 0) SPQ_XSP_LAUNCH(16, 0, 0); else if (x.a8 == 1) SPQ_XSP_LAUNCH(16, 1, 0); else SPQ_XSP_LAUNCH(16, 2, 1); }
+        else if (r32) { if (x.a8 == 0) SPQ_XSP_LAUNCH(32, 0, 0); else SPQ_XSP_LAUNCH(32, 2, 1); }
+        else { if (x.a8 == 0) SPQ_XSP_LAUNCH(16, 0, 0); else SPQ_XSP_LAUNCH(16, 2, 1); }
 #undef SPQ_XSP_LAUNCH
-      } else
+      } else {
 #define SPQ_XS_LAUNCH(R, A8, LN) xpass_stream_kernel<R, A8, LN><<<(unsigned)((a->M + R - 1) / R), R * 16, xs_lds(R), st>>>(x)
-#define SPQ_XS_PICK(R) do { if (ln) { if (x.a8 == 0) SPQ_XS_LAUNCH(R, 0, true); else if (x.a8 == 1) SPQ_XS_LAUNCH(R, 1, true); else SPQ_XS_LAUNCH(R, 2, true); } \
-                            else { if (x.a8 == 0) SPQ_XS_LAUNCH(R, 0, false); else if (x.a8 == 1) SPQ_XS_LAUNCH(R, 1, false); else SPQ_XS_LAUNCH(R, 2, false); } } while (0)
-      if (x.limbs) { if (r32) SPQ_XS_LAUNCH(32, 3, false); else SPQ_XS_LAUNCH(16, 3, false); }
-      else if (r32) SPQ_XS_PICK(32); else SPQ_XS_PICK(16);
+#define SPQ_XS_PICK(R) do { if (ln) { if (x.a8 == 0) SPQ_XS_LAUNCH(R, 0, true); else SPQ_XS_LAUNCH(R, 2, true); } \
+                            else { if (x.a8 == 0) SPQ_XS_LAUNCH(R, 0, false); else SPQ_XS_LAUNCH(R, 2, false); } } while (0)
+        if (x.limbs) { if (r32) SPQ_XS_LAUNCH(32, 3, false); else SPQ_XS_LAUNCH(16, 3, false); }
+        else if (r32) SPQ_XS_PICK(32); else SPQ_XS_PICK(16);
 #undef SPQ_XS_PICK
 #undef SPQ_XS_LAUNCH
-    } else if (x.ascale && a->r > 0) xpass_panel16_kernel<<<xgrid, 512, XP16_LDS, st>>>(x);
-    else if (use_rows16 && prep_rows > 0) {
-      const unsigned xg16 = (unsigned)((a->M + XR16 - 1) / XR16);
-      if (pa.nl == 1) xpass_rows16_kernel<2><<<xg16, 256, XP16R_LDS, st>>>(x, pa, prep_rows);
-      else xpass_rows16_kernel<1><<<xg16, 256, XP16R_LDS, st>>>(x, pa, prep_rows);
-    } else if (use_rows16)
-      xpass_rows16_kernel<0><<<(unsigned)((a->M + XR16 - 1) / XR16), 256, XP16R_LDS, st>>>(x, pa, 0);
-    else if (xgrid >= 2 * gemm_grid(1 << 30)) xpass_panel_kernel<XP_CHUNKS_SMALL><<<xgrid, 512, xp_lds(XP_CHUNKS_SMALL), st>>>(x);
+      }
+    } else if (xgrid >= 2 * gemm_grid(1 << 30)) xpass_panel_kernel<XP_CHUNKS_SMALL><<<xgrid, 512, xp_lds(XP_CHUNKS_SMALL), st>>>(x);
     else xpass_panel_kernel<XP_CHUNKS><<<xgrid, 512, XP_LDS, st>>>(x);
   } else if (L.Rp <= 64) xpass_kernel<2><<<xgrid, 256, 0, st>>>(x);
   else xpass_kernel<4><<<xgrid, 256, 0, st>>>(x);
@@ -2997,23 +2025,6 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
     return check_launch("spq_linear_lora_fwd(gemm_i8)");
   }
-  if (a8) {
-    GemmU8Args u;
-    u.qx = reinterpret_cast<const unsigned char*>(x.qx); u.thi = x.thi; u.tlo = x.tlo;
-    u.Whi = (const _Float16*)(wp + P.off_whi); u.Wlo = (const _Float16*)(wp + P.off_wlo);
-    u.Bhi = (const _Float16*)(wp + P.off_bhi); u.Blo = (const _Float16*)(wp + P.off_blo);
-    u.rowinv = x.rowinv; u.rowscale = a->w_rowscale; u.bias = a->bias; u.y = a->y;
-    u.M = (int)a->M; u.N = (int)a->N; u.Kp = (int)L.Kp; u.Rp = lora_up ? (int)L.Rp : 0;
-    u.tiles_m = (int)(L.Mp / GM); u.tiles_n = (int)(P.Np / GN);
-    if (AttrOnce once(2); once.first) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_u8x2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, U8_LDS);
-      if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %d B): %s", U8_LDS, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
-    }
-    if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
-    gemm_u8x2_kernel<0><<<gemm_grid(u.tiles_m * u.tiles_n), GEMM_THREADS, U8_LDS, st>>>(u);
-    if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
-    return check_launch("spq_linear_lora_fwd(gemm_u8x2)");
-  }
   GemmF16Args g;
   g.qx = x.qx; g.thi = x.thi; g.tlo = x.tlo;
   g.Whi = (const _Float16*)(wp + P.off_whi); g.Wlo = (const _Float16*)(wp + P.off_wlo);
@@ -3042,79 +2053,39 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     if (!limbs_out) g.lv_qhi = (float)((1 << (a->out_bits - 1)) - 1);
   }
   if (AttrOnce once(3); once.first) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16x2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       GEMM_LDS);
-    if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %d B): %s", GEMM_LDS, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_s16_kernel<0, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(LDS %d B): %s", T128_LDS, hipGetErrorString(e)); return SPQ_ERR_LAUNCH; }
+#define SPQ_T128_ATTR(AL, EPI, LV) (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<AL, EPI, LV>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS)
+    SPQ_T128_ATTR(2, 0, 0); SPQ_T128_ATTR(1, 1, 0); SPQ_T128_ATTR(2, 1, 0);
+    SPQ_T128_ATTR(1, 0, 1); SPQ_T128_ATTR(2, 0, 1); SPQ_T128_ATTR(1, 1, 1); SPQ_T128_ATTR(2, 1, 1);
+    SPQ_T128_ATTR(1, 0, 2); SPQ_T128_ATTR(2, 0, 2); SPQ_T128_ATTR(1, 1, 2); SPQ_T128_ATTR(2, 1, 2);
+#undef SPQ_T128_ATTR
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+  }
+  g.split = sk; g.sk_cnt = (int*)(ws + L.off_skcnt); g.sk_part = (float*)(ws + L.off_skpart);
+  if (sk > 1 && !sk_zeroed && hipMemsetAsync(g.sk_cnt, 0, (size_t)(2 * sk_nwg) * sizeof(int), st) != hipSuccess) {
+    set_error("spq_linear_lora_fwd: hipMemsetAsync(split-K counters) failed"); (void)hipGetLastError(); return SPQ_ERR_LAUNCH;
   }
   if (a->ev_gemm_begin) (void)hipEventRecord((hipEvent_t)a->ev_gemm_begin, st);
-  // default: the 16x16x32 variant (measured 85 us vs 90 us for the 32x32x16 one on the headline shape, same cycles per
-  // FLOP: the chip holds a higher clock on it); SPQ_MFMA16=0 selects the 32x32x16 kernel (the one tools/gemm_bench dissects)
-  static int mfma16 = -1;
-  if (mfma16 < 0) {
-    const char* e = getenv("SPQ_MFMA16");
-    mfma16 = (e && e[0] == '0') ? 0 : 1;
-  }
-  if (x3 && !mfma16) { set_error("spq_linear_lora_fwd: SPQ_PATH_F16X3 needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
+  // ONE contraction kernel for every shape (128 x 128 tiles, three workgroups per CU); the 256 x 128 persistent kernels of round 1
+  // live in tools/variants/gemm_256x128.h (measured slower at every shape of SURVEY 8(d): config 3 1.466 -> 1.356 ms, config 5
+  // 27.8 -> 27.4 ms)
   const bool gelu = a->epilogue == SPQ_EPILOGUE_GELU;
-  if (gelu && !mfma16) { set_error("spq_linear_lora_fwd: the GELU epilogue needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
-  static int t128 = -1;
-  if (t128 < 0) {
-    const char* e = getenv("SPQ_GEMM_T128");
-    t128 = !e ? 2 : (e[0] == '1' ? 1 : 0);     // unset: by shape (below), 1: always, 0: never
-  }
-  if ((a->N & 3) != 0 && !mfma16) { set_error("spq_linear_lora_fwd: N %% 4 != 0 needs the 16x16x32 kernel (unset SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
-  // measured (tools/config_bench.py), round 2 with three workgroups per CU taking the issue priorities in turn: the 128x128
-  // kernel wins at every shape of SURVEY 8(d) -- config 3 (M = 32768) 1.466 -> 1.356 ms over the four linears, config 5 (the
-  // three-product path) 27.8 -> 27.4 ms -- so the 256x128 kernel is what SPQ_GEMM_T128=0 selects
-  const bool use_t128 = t128 != 0;
-  if (use_t128 && mfma16 && (a->N & 3) == 0) {
-    const int ntiles = 2 * g.tiles_m * g.tiles_n;
-    const unsigned cus2 = T128_WGS * gemm_grid(1 << 30);
-    const unsigned grid128 = (unsigned)ntiles < cus2 ? (unsigned)ntiles : cus2;
-    if (g.lv && g.lv_lo) {
-      if (x3 && gelu) gemm_f16x2_t128_kernel<2, 1, 2><<<grid128, 256, T128_LDS, st>>>(g);
-      else if (x3) gemm_f16x2_t128_kernel<2, 0, 2><<<grid128, 256, T128_LDS, st>>>(g);
-      else if (gelu) gemm_f16x2_t128_kernel<1, 1, 2><<<grid128, 256, T128_LDS, st>>>(g);
-      else gemm_f16x2_t128_kernel<1, 0, 2><<<grid128, 256, T128_LDS, st>>>(g);
-    }
-    else if (g.lv) {
-      if (x3 && gelu) gemm_f16x2_t128_kernel<2, 1, 1><<<grid128, 256, T128_LDS, st>>>(g);
-      else if (x3) gemm_f16x2_t128_kernel<2, 0, 1><<<grid128, 256, T128_LDS, st>>>(g);
-      else if (gelu) gemm_f16x2_t128_kernel<1, 1, 1><<<grid128, 256, T128_LDS, st>>>(g);
-      else gemm_f16x2_t128_kernel<1, 0, 1><<<grid128, 256, T128_LDS, st>>>(g);
-    }
-    else if (x3 && gelu) gemm_f16x2_t128_kernel<2, 1><<<grid128, 256, T128_LDS, st>>>(g);
-    else if (x3) gemm_f16x2_t128_kernel<2, 0><<<grid128, 256, T128_LDS, st>>>(g);
-    else if (gelu) gemm_f16x2_t128_kernel<1, 1><<<grid128, 256, T128_LDS, st>>>(g);
-    else gemm_f16x2_t128_kernel<1, 0><<<grid128, 256, T128_LDS, st>>>(g);
-    if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
-    return check_launch("spq_linear_lora_fwd(gemm_t128)");
-  }
-  if (g.lv) { set_error("spq_linear_lora_fwd: the levels-out store needs the 128x128 contraction kernel (unset SPQ_GEMM_T128 / SPQ_MFMA16)"); return SPQ_ERR_UNSUPPORTED; }
-  const unsigned grid = gemm_grid(g.tiles_m * g.tiles_n);
-  if (mfma16 && x3 && gelu) gemm_f16x2_s16_kernel<0, 2, 1><<<grid, GEMM_THREADS, GEMM_LDS, st>>>(g);
-  else if (mfma16 && x3) gemm_f16x2_s16_kernel<0, 2><<<grid, GEMM_THREADS, GEMM_LDS, st>>>(g);
-  else if (mfma16 && gelu) gemm_f16x2_s16_kernel<0, 1, 1><<<grid, GEMM_THREADS, GEMM_LDS, st>>>(g);
-  else if (mfma16) gemm_f16x2_s16_kernel<0, 1><<<grid, GEMM_THREADS, GEMM_LDS, st>>>(g);
-  else gemm_f16x2_kernel<0><<<gemm_grid(g.tiles_m * g.tiles_n), GEMM_THREADS, GEMM_LDS, st>>>(g);
+  const int ntiles = 2 * g.tiles_m * g.tiles_n * sk;
+  const unsigned cus3 = (sk > 1 ? 2 : 1) * T128_WGS * gemm_grid(1 << 30);    // split-K: one unit per workgroup
+  const unsigned grid128 = (unsigned)ntiles < cus3 ? (unsigned)ntiles : cus3;
+#define SPQ_T128_LAUNCH(AL, EPI, LV) gemm_f16x2_t128_kernel<AL, EPI, LV><<<grid128, 256, T128_LDS, st>>>(g)
+#define SPQ_T128_PICK(LV) do { if (x3 && gelu) SPQ_T128_LAUNCH(2, 1, LV); else if (x3) SPQ_T128_LAUNCH(2, 0, LV); \
+                               else if (gelu) SPQ_T128_LAUNCH(1, 1, LV); else SPQ_T128_LAUNCH(1, 0, LV); } while (0)
+  if (g.lv && g.lv_lo) SPQ_T128_PICK(2);
+  else if (g.lv) SPQ_T128_PICK(1);
+  else if (sk > 1) { if (x3) gemm_f16x2_t128_kernel<2, 0, 0, true><<<grid128, 256, T128_LDS, st>>>(g); else gemm_f16x2_t128_kernel<1, 0, 0, true><<<grid128, 256, T128_LDS, st>>>(g); }
+  else SPQ_T128_PICK(0);
+#undef SPQ_T128_PICK
+#undef SPQ_T128_LAUNCH
   if (a->ev_gemm_end) (void)hipEventRecord((hipEvent_t)a->ev_gemm_end, st);
-  return check_launch("spq_linear_lora_fwd(gemm_f16x2)");
+  return check_launch("spq_linear_lora_fwd(gemm_t128)");
 }
 
 }  // namespace spq

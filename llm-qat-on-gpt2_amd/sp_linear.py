@@ -104,7 +104,7 @@ class _LimbGemm:
 
     @staticmethod
     def supported(R: int, C: int) -> bool:
-        return R > 0 and C > 0 and _MFMA16                  # SPQ_PATH_F16X3 lives in the 16x16x32 kernel
+        return R > 0 and C > 0
 
     def _buffers(self, R, C, device):
         if self.key != (R, C, device):
@@ -151,7 +151,7 @@ class _LimbGemm:
                 w_prep=self.w.data_ptr(), w_rowscale=self.rowscale.data_ptr(), bias=None, a_prep=_lib.ptr(down_p),
                 b_prep=None, lora_scaling=0.0, y=out.data_ptr(), workspace=ws.data_ptr(),
                 workspace_bytes=ws.numel() - sws - 256, ev_gemm_begin=None, ev_gemm_end=None, t_out=_lib.ptr(t),
-                a_limb_scale=_lib.ptr(down_scale) if (down is not None and _LORA_DOWN_F16) else None)
+                a_limb_scale=None)
             rc = lib.spq_linear_lora_fwd(ctypes.byref(args), st)
             _lib.check(rc, "spq_linear_lora_fwd(backward)")
         return out if down is None else (out, t)
@@ -159,11 +159,11 @@ class _LimbGemm:
 
 class _Prepared:
     """Weight-side GEMM operands of one bit-width plus the signature of what they were built from."""
-    __slots__ = ("sig", "path", "w", "w_rowscale", "a", "b", "r", "x_limb_scale", "ready", "a_limb_scale", "pending", "keep")
+    __slots__ = ("sig", "path", "w", "w_rowscale", "a", "b", "r", "x_limb_scale", "a_limb_scale", "pending", "keep")
 
     def __init__(self):
         self.sig = None
-        self.w = self.w_rowscale = self.a = self.b = self.x_limb_scale = self.ready = self.a_limb_scale = None
+        self.w = self.w_rowscale = self.a = self.b = self.x_limb_scale = self.a_limb_scale = None
         self.pending = None      # _lib.PrepareArgs not launched yet: the forward that follows makes the operands itself
         self.keep = None         # tensors the pending struct points into
         self.r = 0
@@ -212,8 +212,6 @@ class SPLinearWithLoRA(nn.Module):
         self._prepared = {}
         self._gemm_events = None                  # (hipEvent_t, hipEvent_t) around the dominant kernel, for bench.py
         self.backward_limbs = True                # d/dx on the f16 MFMA limb kernel (False: fp32 MFMA kernel)
-        # weight-side limb split on a side stream, under the activation pass (opt-in: measured slower)
-        self.overlap_prepare = os.environ.get('SPQ_OVERLAP_PREPARE', '0') == '1'
         # True (default): a re-quantising forward (training mode, or cache_operands off) hands the weight-side preparation to the
         # forward call (spq_fwd_args.prepare).  Where the streaming activation kernel runs, the row work then rides in the SAME
         # launch as extra workgroups beside the activation workgroups (xpass_stream_prep_kernel; FQ(A)^T, which the pass
@@ -297,7 +295,7 @@ class SPLinearWithLoRA(nn.Module):
         if lora.enabled and (lora.quantize_A.collecting_stats or lora.quantize_B.collecting_stats or lora.rank > 64):
             return False
         K = self.in_features
-        if K % 64 != 0 or K > 1024 or tuple(norm.normalized_shape) != (K,) or x.shape[-1] != K or _LORA_DOWN_F16:
+        if K % 64 != 0 or K > 1024 or tuple(norm.normalized_shape) != (K,) or x.shape[-1] != K:
             return False
         use_lora = (not self.calibration_mode) and lora.enabled and lora.scaling != 0
         return self._choose_path(qx, qw, lora, use_lora, 1) in (_lib.PATH_F16X2, _lib.PATH_F16X3, _lib.PATH_I8)
@@ -399,18 +397,10 @@ class SPLinearWithLoRA(nn.Module):
             nw, nb = norm.weights[str(norm.current_precision)], norm.biases[str(norm.current_precision)]
             a.ln_weight, a.ln_bias, a.ln_eps = nw.data_ptr(), nb.data_ptr(), float(norm.eps)
             self._norm_fused = True
-        if activation == 'gelu' and ((prep.path in (_lib.PATH_F16X2, _lib.PATH_F16X3) and _MFMA16)
-                                     or prep.path == _lib.PATH_I8):
+        if activation == 'gelu' and prep.path in (_lib.PATH_F16X2, _lib.PATH_F16X3, _lib.PATH_I8):
             a.epilogue = _lib.EPILOGUE_GELU
             self._activation_fused = True
         with _lib.on_device(x.device):
-            if prep.ready is not None:                      # weight planes are being written on the side stream
-                a.stage = _lib.STAGE_ACTIVATIONS
-                rc = lib.spq_linear_lora_fwd(ctypes.byref(a), st)
-                _lib.check(rc, "spq_linear_lora_fwd(activations)")
-                torch.cuda.current_stream(x.device).wait_event(prep.ready)
-                prep.ready = None
-                a.stage = _lib.STAGE_CONTRACTION
             rc = lib.spq_linear_lora_fwd(ctypes.byref(a), st)
         prep.pending = prep.keep = None
         _lib.check(rc, "spq_linear_lora_fwd")
@@ -430,12 +420,12 @@ class SPLinearWithLoRA(nn.Module):
     def _choose_path(self, qx, qw, lora, use_lora, quantize_input):
         """SPQ_PATH_F16X2 (exact integer levels x 2-limb fp16 weights) whenever the input quantizer allows it:
         symmetric minmax, <= 12 bits, actually quantising; otherwise the always-valid fp32-MFMA path."""
-        shape_ok = (not use_lora or lora.rank <= 128) and (self.out_features % 4 == 0 or _MFMA16)
+        shape_ok = not use_lora or lora.rank <= 128
         f16_ok = (quantize_input and qx.quantizer_type == 'minmax' and qx.symmetric and 2 <= qx.num_bits <= 12
                   and shape_ok)
         # any other calibrated input quantizer (log, asymmetric, > 12 bit): FQ(x) as two fp16 limbs
         x3_ok = (quantize_input and not f16_ok and qx.quantizer_type in _lib.QTYPE_CODE and 1 <= qx.num_bits <= 16
-                 and shape_ok and _MFMA16)               # the two-limb activation stages exist in the 16x16x32 kernel only
+                 and shape_ok)
         # int8 matrix cores (SPQ_PATH_I8): levels of <= 8 bits x the weight's own integer levels -- one product per algorithmic
         # product at twice the f16 rate -- valid when those levels exist (symmetric minmax weights, <= 8 bit) and the input scale
         # is per tensor (it then leaves the sum).  Measured 50-53 us against ~80 us for the contraction at the c_fc shape.
@@ -454,10 +444,8 @@ class SPLinearWithLoRA(nn.Module):
             return _lib.PATH_F16X2 if f16_ok else (_lib.PATH_F16X3 if x3_ok else _lib.PATH_F32)
         if self.operand_path == _lib.PATH_F16X3:
             return _lib.PATH_F16X3 if (x3_ok or f16_ok) else _lib.PATH_F32
-        if self.operand_path in (_lib.PATH_F16X2, _lib.PATH_U8X2) and not f16_ok:
+        if self.operand_path == _lib.PATH_F16X2 and not f16_ok:
             return _lib.PATH_F32            # e.g. calibration forwards (raw x) of a layer pinned to F16X2
-        if self.operand_path == _lib.PATH_U8X2 and (qx.num_bits > 8 or not (use_lora and lora is not None and lora.rank > 0)):
-            return _lib.PATH_F16X2          # (no LoRA term: a NaN activation must stay visible, see above)
         return self.operand_path
 
     def _operands(self, key, qx, qw, lora, use_lora, quantize_input):
@@ -543,25 +531,9 @@ class SPLinearWithLoRA(nn.Module):
         else:
             sx_t = qx.qparams_for(K)[0]
             prep.x_limb_scale = None
-        # LoRA-down product of the activation pass on the f16 matrix pipe: FQ(A)^T is split into limbs of FQ(A) * 2^S there
-        prep.a_limb_scale = _limb_scale(qa) if (use_lora and _LORA_DOWN_F16 and qa.num_bits < 32) else None
-        # The limb planes of W and B are needed by the contraction only, FQ(A)^T already by the activation pass: with
-        # overlap on, FQ(A)^T is made on the current stream and the (much larger) W/B job on a side stream, so it runs
-        # under the activation pass of the forward that follows; that forward waits for `prep.ready` before its contraction.
-        overlap = self.overlap_prepare and use_lora and not defer
+        prep.a_limb_scale = None
         cur = torch.cuda.current_stream(W.device)
-        prep.ready = None
         prep.pending = prep.keep = None
-        if overlap:
-            with torch.cuda.device(W.device):
-                rc = lib.spq_fakequant_transposed(
-                    A.data_ptr(), K, r, sa.data_ptr(), za.data_ptr(), 1 if sa.numel() > 1 else 0,
-                    int(qa.num_bits), _lib.QTYPE_CODE[qa.quantizer_type], 1 if qa.symmetric else 0, 1.0,
-                    prep.a.data_ptr(), cur.cuda_stream)
-            _lib.check(rc, "spq_fakequant_transposed")
-            side = _side_stream(W.device)
-            side.wait_stream(cur)                          # the previous forward's contraction may still read the planes
-            A = None
         pa = _lib.PrepareArgs(
             W=W.data_ptr(), N=N, K=K, sw=sw.data_ptr(), zw=zw.data_ptr(), w_per_channel=1 if sw.numel() > 1 else 0,
             w_bits=int(qw.num_bits), w_qtype=_lib.QTYPE_CODE[qw.quantizer_type], w_symmetric=1 if qw.symmetric else 0,
@@ -576,33 +548,15 @@ class SPLinearWithLoRA(nn.Module):
         if defer:
             prep.pending, prep.keep = pa, (W, B, A, sw, zw, sb, zb, sa, za, sx_t)
         else:
-            with torch.cuda.device(W.device), torch.cuda.stream(side if overlap else cur):
-                rc = lib.spq_prepare_f16x2_args(ctypes.byref(pa), _lib.stream_ptr(W.device))
-                if overlap:
-                    prep.ready = torch.cuda.Event()
-                    prep.ready.record(side)
+            with torch.cuda.device(W.device):
+                rc = lib.spq_prepare_f16x2_args(ctypes.byref(pa), cur.cuda_stream)
             _lib.check(rc, "spq_prepare_f16x2")
         prep.b = prep.w      # LoRA-B limbs live inside the same buffer
 
 
-_MFMA16 = os.environ.get('SPQ_MFMA16', '1')[:1] != '0'      # the library's kernel choice (spq_f16x2.hip)
-_LIMB_PATHS = (_lib.PATH_F16X2, _lib.PATH_U8X2, _lib.PATH_F16X3, _lib.PATH_I8)
+_LIMB_PATHS = (_lib.PATH_F16X2, _lib.PATH_F16X3, _lib.PATH_I8)
 # SPQ_AUTO_I8=0: PATH_AUTO never picks the int8 operand path (then: F16X2 wherever it would be valid)
 _AUTO_I8 = os.environ.get('SPQ_AUTO_I8', '1')[:1] != '0'
-# SPQ_LORA_DOWN_F16=1: x . FQ(A) of the activation pass as fp16 limbs on the f16 matrix pipe (xpass_panel16_kernel).  Off by default:
-# its 200 VGPRs allow one workgroup per CU, and two resident workgroups of the fp32-MFMA kernel hide more latency
-_LORA_DOWN_F16 = os.environ.get('SPQ_LORA_DOWN_F16', '0') == '1'
-_side_streams = {}
-
-
-def _side_stream(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    st = _side_streams.get(key)
-    if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=device)
-    return st
-
-
 _ones_cache = {}
 
 

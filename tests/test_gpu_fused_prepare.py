@@ -48,23 +48,17 @@ CASES = [
 
 
 # how the library serves spq_fwd_args.prepare: "role" (default) = extra workgroups of the streaming activation launch where that
-# kernel runs; "inpass" = the earlier variant, rows spread over the 16-row activation kernel's own workgroups; "launch" = always
-# the ordinary preparation launch, issued by the library
-MODES = {"role": {}, "inpass": {"SPQ_PREP_ROLE": "0", "SPQ_PREP_INPASS": "1"}, "launch": {"SPQ_PREP_ROLE": "0"}}
+# kernel runs; "launch" = always the ordinary preparation launch, issued by the library
+MODES = {"role": {}, "launch": {"SPQ_PREP_ROLE": "0"}}
 
 
 @pytest.fixture(params=list(MODES))
-def prep_mode(request):
+def prep_mode(request, pkg):
     import os
-    old = {k: os.environ.get(k) for k in ("SPQ_PREP_ROLE", "SPQ_PREP_INPASS")}
-    for k in old:
-        os.environ.pop(k, None)
-    os.environ.update(MODES[request.param])
+    old = os.environ.get("SPQ_PREP_ROLE")
+    pkg._lib.set_switch("SPQ_PREP_ROLE", MODES[request.param].get("SPQ_PREP_ROLE"))
     yield request.param
-    for k, v in old.items():
-        os.environ.pop(k, None)
-        if v is not None:
-            os.environ[k] = v
+    pkg._lib.set_switch("SPQ_PREP_ROLE", old)
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c))

@@ -89,10 +89,10 @@ def test_fused_forward_nan_row(pkg, bits, qtype):
     assert torch.equal(yn[~nan_rows], y[~nan_rows])
 
 
-@pytest.mark.parametrize("path", ["I8", "U8X2", "AUTO"])
+@pytest.mark.parametrize("path", ["I8", "AUTO"])
 @pytest.mark.parametrize("lora_on", [True, False])
 def test_fused_forward_nan_row_byte_level_paths(pkg, path, lora_on):
-    """the byte-level operand paths (per-tensor input scale: what PATH_AUTO picks for every evaluation-loader model)
+    """the byte-level operand path (int8 levels; per-tensor input scale: what PATH_AUTO picks for every evaluation-loader model)
     cannot hold a NaN level.  With the LoRA branch the fp32 LoRA-down product carries the NaN; without it (calibration_mode,
     disabled adapter) the layer must not take a byte-level path: either way the token's whole output row is NaN, as F.linear's."""
     from oracle import ref_cpu as O
@@ -105,7 +105,7 @@ def test_fused_forward_nan_row_byte_level_paths(pkg, path, lora_on):
     layer = layer.to(DEV).eval()
     layer.set_precision(8)
     pkg.calibrate_layer(layer, 8, [x0.to(DEV), x1.to(DEV)])
-    layer.operand_path = {"I8": pkg._lib.PATH_I8, "U8X2": pkg._lib.PATH_U8X2, "AUTO": pkg._lib.PATH_AUTO}[path]
+    layer.operand_path = {"I8": pkg._lib.PATH_I8, "AUTO": pkg._lib.PATH_AUTO}[path]
     if not lora_on:
         layer.lora_adapters["8bit"].enabled = False
     x = x0.clone().to(DEV)

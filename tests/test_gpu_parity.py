@@ -115,13 +115,13 @@ def test_quantizer_case(pkg, name):
     check_levels(q, t["xt"].to(DEV), t["fq_xt"], t["lv_xt"], meta["qtype"], name)
 
 
-@pytest.mark.parametrize("path", ["auto", "f32", "u8x2", "f16x3"])
+@pytest.mark.parametrize("path", ["auto", "f32", "f16x2", "f16x3"])
 @pytest.mark.parametrize("name", LAYER_CASES)
 def test_layer_case(pkg, name, path):
     meta, t = load_case(name)
-    if path == "u8x2" and meta["qtype"] != "minmax":
-        pytest.skip("byte levels exist for minmax only; log cases run as auto (two-limb path), f32 and f16x3")
-    layer, key = build_layer(pkg, meta, t, {"auto": pkg._lib.PATH_AUTO, "f32": pkg._lib.PATH_F32, "u8x2": pkg._lib.PATH_U8X2,
+    if path == "f16x2" and meta["qtype"] != "minmax":
+        pytest.skip("integer fp16 levels exist for minmax only; log cases run as auto (two-limb path), f32 and f16x3")
+    layer, key = build_layer(pkg, meta, t, {"auto": pkg._lib.PATH_AUTO, "f32": pkg._lib.PATH_F32, "f16x2": pkg._lib.PATH_F16X2,
                                             "f16x3": pkg._lib.PATH_F16X3}[path])
     lora = layer.lora_adapters[key]
     quants = {"qx": layer.quantizers_input[key], "qw": layer.quantizers_weight[key], "qA": lora.quantize_A,
@@ -164,9 +164,9 @@ def test_layer_case(pkg, name, path):
     f16_ok = qt == "minmax" and meta["bits"] <= 12
     i8_ok = qt == "minmax" and meta["bits"] <= 8 and not meta["per_channel"]      # per-tensor scale: the int8 matrix cores
     want = {"auto": pkg._lib.PATH_I8 if i8_ok else (pkg._lib.PATH_F16X2 if f16_ok else pkg._lib.PATH_F16X3), "f32": pkg._lib.PATH_F32,
-            "f16x3": pkg._lib.PATH_F16X3, "u8x2": None}[path]
-    if path == "u8x2":
-        want = pkg._lib.PATH_U8X2 if meta["bits"] <= 8 else (pkg._lib.PATH_F16X2 if meta["bits"] <= 12 else pkg._lib.PATH_F32)
+            "f16x3": pkg._lib.PATH_F16X3, "f16x2": None}[path]
+    if path == "f16x2":                                   # pinned: also where PATH_AUTO would take the int8 path
+        want = pkg._lib.PATH_F16X2 if meta["bits"] <= 12 else pkg._lib.PATH_F32
     assert layer._last_path == want, (layer._last_path, want)
     tol = 1e-5   # minmax and log alike (tools/log_tolerance_study.py: the log fixtures sit at <= 0.15 of this bound)
     assert_close_y(y2, t["y_x2"], f"{name}.y_x2", tol)
@@ -233,7 +233,7 @@ def test_error_behaviour(pkg):
         assert torch.allclose(layer(x), torch.nn.functional.linear(x, layer.linear.weight, layer.linear.bias))
 
 
-@pytest.mark.parametrize("path", ["f16x2", "u8x2", "f32"])
+@pytest.mark.parametrize("path", ["f16x2", "f32"])
 def test_headline_shape_against_oracle(pkg, path):
     """BASELINE headline: c_fc 768->3072, 4-bit minmax per-channel, r=64, batch 8 x seq 1024."""
     from oracle import ref_cpu as O
@@ -246,7 +246,7 @@ def test_headline_shape_against_oracle(pkg, path):
         layer.lora_adapters["4bit"].lora_A.copy_(A); layer.lora_adapters["4bit"].lora_B.copy_(B)
     layer = layer.to(DEV).eval()
     layer.set_precision(bits)
-    layer.operand_path = {"f16x2": pkg._lib.PATH_F16X2, "u8x2": pkg._lib.PATH_U8X2, "f32": pkg._lib.PATH_F32}[path]
+    layer.operand_path = {"f16x2": pkg._lib.PATH_F16X2, "f32": pkg._lib.PATH_F32}[path]
     pkg.calibrate_layer(layer, bits, [x0.to(DEV), x1.to(DEV)])
     assert torch.equal(layer.quantizers_input["4bit"].scale.cpu(), ol.qx.scale)
     assert torch.equal(layer.quantizers_weight["4bit"].scale.cpu(), ol.qw.scale)

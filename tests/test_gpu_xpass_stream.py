@@ -22,13 +22,10 @@ def pkg():
 
 
 @pytest.fixture(autouse=True)
-def _restore_env():
+def _restore_env(pkg):
     old = os.environ.get("SPQ_XPASS_STREAM")
     yield
-    if old is None:
-        os.environ.pop("SPQ_XPASS_STREAM", None)
-    else:
-        os.environ["SPQ_XPASS_STREAM"] = old
+    pkg._lib.set_switch("SPQ_XPASS_STREAM", old)
 
 
 def build(pkg, M, K, N, r, bits, per_channel=True, seed=0):
@@ -46,11 +43,16 @@ def build(pkg, M, K, N, r, bits, per_channel=True, seed=0):
     return layer, x0.to(DEV), (W, bias, A, B)
 
 
+def _set(name, value):
+    import llm_qat_on_gpt2_amd as p
+    p._lib.set_switch(name, value)
+
+
 def run_modes(layer, x, modes=("0", "16", "32", "1")):
     out = {}
     with torch.no_grad():
         for m in modes:
-            os.environ["SPQ_XPASS_STREAM"] = m
+            _set("SPQ_XPASS_STREAM", m)
             out[m] = layer(x).clone()
     return out
 
@@ -64,7 +66,6 @@ CASES = [
     (2048, 64, 128, 64, 4, True, "auto"),         # one chunk: no steady state
     (2048, 128, 128, 64, 6, True, "auto"),        # two chunks
     (4096, 768, 256, 64, 8, False, "auto"),       # per-tensor input scale: int8 levels (SPQ_PATH_I8)
-    (4096, 768, 256, 64, 4, True, "u8x2"),        # levels as bytes q + 128
 ]
 
 
@@ -72,17 +73,12 @@ CASES = [
 def test_streaming_pass_matches_the_panel_kernels(pkg, case):
     M, K, N, r, bits, pc, path = case
     layer, x, _ = build(pkg, M, K, N, r, bits, per_channel=pc, seed=K + bits)
-    if path == "u8x2":
-        layer.operand_path = pkg._lib.PATH_U8X2
     out = run_modes(layer, x)
     assert bool(torch.isfinite(out["0"]).all())
-    if M < 16384:                                  # same k-partition of the LoRA-down sum as the 16-row panel kernel: bit-identical
-        for m in ("16", "32", "1"):
-            assert torch.equal(out[m], out["0"]), f"mode {m}: max abs diff {float((out[m] - out['0']).abs().max()):.3e}"
-    else:                                          # the 32-row panel kernel sums the LoRA-down product in another order
-        for m in ("16", "32", "1"):
-            assert_close_y(out[m], out["0"], f"mode {m}", 1e-5)
-        assert torch.equal(out["16"], out["32"]) and torch.equal(out["1"], out["32"])
+    # the panel kernel sums the LoRA-down product in another order (8 k-slices per chunk against 4); the level pass is exact either way
+    for m in ("16", "32", "1"):
+        assert_close_y(out[m], out["0"], f"mode {m}", 1e-5)
+    assert torch.equal(out["16"], out["32"]) and torch.equal(out["1"], out["32"])
 
 
 def _tie_rows(scale, bits, M, gen):
@@ -185,20 +181,14 @@ def test_limb_form_matches_the_panel_kernels(pkg, case):
     old = os.environ.get("SPQ_XPASS_STREAM_LIMBS")
     try:
         with torch.no_grad():
-            os.environ["SPQ_XPASS_STREAM_LIMBS"] = "0"
+            pkg._lib.set_switch("SPQ_XPASS_STREAM_LIMBS", "0")
             y_panel = layer(x).clone()
             assert layer._last_path == pkg._lib.PATH_F16X3
-            os.environ.pop("SPQ_XPASS_STREAM_LIMBS")
+            pkg._lib.set_switch("SPQ_XPASS_STREAM_LIMBS", None)
             y_stream = layer(x).clone()
             layer.cache_operands = False                   # + the weight rows as extra workgroups of the same launch
             y_role = layer(x).clone()
     finally:
-        if old is None:
-            os.environ.pop("SPQ_XPASS_STREAM_LIMBS", None)
-        else:
-            os.environ["SPQ_XPASS_STREAM_LIMBS"] = old
-    if M < 16384:                                  # same k-partition of the LoRA-down sum as the 16-row panel kernel: bit-identical
-        assert torch.equal(y_stream, y_panel), f"max abs diff {float((y_stream - y_panel).abs().max()):.3e}"
-    else:                                          # the 32-row panel kernel sums the LoRA-down product in another order
-        assert_close_y(y_stream, y_panel, "limb stream vs panel", 1e-6)
+        pkg._lib.set_switch("SPQ_XPASS_STREAM_LIMBS", old)
+    assert_close_y(y_stream, y_panel, "limb stream vs panel", 1e-6)   # (the panel kernel sums the LoRA-down product in another order)
     assert torch.equal(y_role, y_stream)

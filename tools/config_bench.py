@@ -8,7 +8,7 @@ import llm_qat_on_gpt2_amd as pkg
 from llm_qat_on_gpt2_amd import synthetic as O          # seeded input generator
 
 dev = 'cuda:0'
-PATHN = {1: 'f32', 2: 'f16x2', 3: 'u8x2', 4: 'f16x3', 5: 'i8'}
+PATHN = {1: 'f32', 2: 'f16x2', 4: 'f16x3', 5: 'i8'}
 
 
 def build(M, K, N, r, bits, qt, pc, seed=0):
@@ -46,7 +46,8 @@ def warm_loop(layer, x, iters):
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument('--out', default='gpurun_out/configs.json'); args = ap.parse_args()
+    ap = argparse.ArgumentParser(); ap.add_argument('--out', default='gpurun_out/configs.json')
+    ap.add_argument('--configs', default='2,3,4,5', help='comma-separated subset of SURVEY 8(d) configs'); args = ap.parse_args()
     flush = torch.empty(512 * 1024 * 1024 // 4, device=dev)
     S, MED = 768, 1024
     cases = [  # config, name, M, K, N, r, bits, qtype, per_channel, repeats of this layer in the config
@@ -66,6 +67,7 @@ def main():
         ('5', 'medium mlp c_proj log 6-bit', 8192, 4 * MED, MED, 64, 6, 'log', True, 24),
     ]
     rows = []
+    cases = [c for c in cases if c[0] in args.configs.split(',')]
     for cfg, name, M, K, N, r, bits, qt, pc, rep in cases:
         layer, x = build(M, K, N, r, bits, qt, pc)
         flop = 2 * M * (K * N + K * r + r * N)

@@ -4,6 +4,8 @@
 #include <vector>
 #include <random>
 #include "../llm-qat-on-gpt2_amd/csrc/spq_f16x2.hip"
+#include "variants/gemm_256x128.h"     // the round-1 kernels this tool dissects (no longer in the library)
+#include "variants/gemm_u8x2.h"
 namespace spq {
 void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fprintf(stderr, "\n"); }
 int check_launch(const char* what) { hipError_t e = hipGetLastError(); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return -2; } return 0; }
