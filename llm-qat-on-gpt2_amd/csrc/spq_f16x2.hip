@@ -1007,9 +1007,11 @@ __device__ __forceinline__ void xpass_stream_body(const XPassArgs& a, char* xsm,
   const int64_t a_step = (int64_t)4 * NW * a.K;
   // the chunk's constants: wave 0 brings the 64 scales, wave 1 / 2 the LayerNorm weight / bias, the others a dummy line
   const int auxw = ws < 3 && rg == 0 ? ws : 3;
-  static_assert(!(LN && A8 == 3), "the limb form has no LayerNorm prologue");
+  // aux lines: 0 scales, 1 / 2 LayerNorm weight / bias, 3 the limb form's zero points (log: minima) when LayerNorm is on too (else
+  // line 1).  Line 3 is written by every wave that has no line of its own -- with the same bytes.
+  constexpr int ZP_LINE = LN ? 3 : 1;
   const float* aux_src = (auxw == 0 && a.x_pc) ? a.sx + lane : (LN && auxw == 1) ? a.ln_w + lane : (LN && auxw == 2) ? a.ln_b + lane
-                         : (A8 == 3 && auxw == 1 && a.x_pc) ? a.zx + lane : nullptr;
+                         : (A8 == 3 && auxw == ZP_LINE && a.x_pc) ? a.zx + lane : nullptr;
   auto issue = [&](int c, int slot) {
     char* s = xsm + slot * SLOT;
     if (!(SPQ_XP_DIAG & 8) || c < 2) glds16(x_src + c * 64, s + w * 1024); else glds4(x_src, s + XS_X + XS_A + 768);
@@ -1083,7 +1085,7 @@ __device__ __forceinline__ void xpass_stream_body(const XPassArgs& a, char* xsm,
     f32x4 sc = xs_ld16(aux + kof * 4);
     if (!a.x_pc) { sc.x = s_pt; sc.y = s_pt; sc.z = s_pt; sc.w = s_pt; }
     if (A8 == 3) {                                          // limb form: MFMAs on the raw x, FQ + limb split of my four elements
-      f32x4 zp = xs_ld16(aux + 256 + kof * 4);
+      f32x4 zp = xs_ld16(aux + ZP_LINE * 256 + kof * 4);
       if (!a.x_pc) { zp.x = z_pt; zp.y = z_pt; zp.z = z_pt; zp.w = z_pt; }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -1910,8 +1912,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   bool sk_zeroed = false;
   x.zero_ptr = nullptr; x.zero_n = 0;
   const int stream16 = sw.stream;
-  // (the limb form of the streaming kernel has no LayerNorm prologue)
-  const bool stream_ok = panel_ok && stream16 && a->r > 0 && (!x.limbs || (sw.stream_limbs && !a->ln_weight && a->quantize_input)) && !x.lora_fq;
+  const bool stream_ok = panel_ok && stream16 && a->r > 0 && (!x.limbs || (sw.stream_limbs && a->quantize_input)) && !x.lora_fq;
   bool role_prep = false;                                  // the row work as extra workgroups of the streaming activation launch
   if (a->prepare && do_xpass) {
     bool wave_ok = false;
@@ -1954,7 +1955,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
 #define SPQ_XS_ATTR(R, A8, LN) (void)hipFuncSetAttribute((const void*)xpass_stream_kernel<R, A8, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, xs_lds(R))
         SPQ_XS_ATTR(16, 0, false); SPQ_XS_ATTR(16, 2, false); SPQ_XS_ATTR(16, 0, true); SPQ_XS_ATTR(16, 2, true);
         SPQ_XS_ATTR(32, 0, false); SPQ_XS_ATTR(32, 2, false); SPQ_XS_ATTR(32, 0, true); SPQ_XS_ATTR(32, 2, true);
-        SPQ_XS_ATTR(16, 3, false); SPQ_XS_ATTR(32, 3, false);
+        SPQ_XS_ATTR(16, 3, false); SPQ_XS_ATTR(32, 3, false); SPQ_XS_ATTR(16, 3, true); SPQ_XS_ATTR(32, 3, true);
 #undef SPQ_XS_ATTR
       }
       // 32-row workgroups halve the FQ(A)^T traffic through L2; taken once they still cover every CU
@@ -1978,7 +1979,8 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
 #define SPQ_XS_LAUNCH(R, A8, LN) xpass_stream_kernel<R, A8, LN><<<(unsigned)((a->M + R - 1) / R), R * 16, xs_lds(R), st>>>(x)
 #define SPQ_XS_PICK(R) do { if (ln) { if (x.a8 == 0) SPQ_XS_LAUNCH(R, 0, true); else SPQ_XS_LAUNCH(R, 2, true); } \
                             else { if (x.a8 == 0) SPQ_XS_LAUNCH(R, 0, false); else SPQ_XS_LAUNCH(R, 2, false); } } while (0)
-        if (x.limbs) { if (r32) SPQ_XS_LAUNCH(32, 3, false); else SPQ_XS_LAUNCH(16, 3, false); }
+        if (x.limbs && ln) { if (r32) SPQ_XS_LAUNCH(32, 3, true); else SPQ_XS_LAUNCH(16, 3, true); }
+        else if (x.limbs) { if (r32) SPQ_XS_LAUNCH(32, 3, false); else SPQ_XS_LAUNCH(16, 3, false); }
         else if (r32) SPQ_XS_PICK(32); else SPQ_XS_PICK(16);
 #undef SPQ_XS_PICK
 #undef SPQ_XS_LAUNCH

@@ -110,7 +110,8 @@ def test_levels_on_rounding_ties(pkg, bits, pc):
     lv_ref = torch.clamp(torch.round(x / scale[None, :]), -(2 ** (bits - 1) - 1), 2 ** (bits - 1) - 1)   # IEEE quotient, ties to even
     assert 0.1 < float(((x / scale[None, :]) % 1 == 0.5).float().mean()) < 0.6                          # the ties are really there
     out = run_modes(layer, x.to(DEV), modes=("0", "32", "16"))
-    assert torch.equal(out["32"], out["0"]) and torch.equal(out["16"], out["0"])
+    assert torch.equal(out["32"], out["16"])
+    assert_close_y(out["32"], out["0"], "stream vs panel", 1e-6)      # (the LoRA-down sum in another order; one wrong level would be ~1e-2)
     # and against the checker: same levels -> y within the bound
     lora = layer.lora_adapters[key]
 
