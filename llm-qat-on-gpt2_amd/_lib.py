@@ -107,6 +107,8 @@ def load():
             "Run `python -c \"import __graft_entry__ as g; g.build()\"` at the repo root.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if name.startswith("spq_debug_") and not hasattr(lib, name):
+            continue                                      # (an older build loaded through SPQ_LIB for an A/B)
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
@@ -121,7 +123,8 @@ def set_switch(name: str, value):
         os.environ.pop(name, None)
     else:
         os.environ[name] = str(value)
-    check(load().spq_debug_reload_switches(), "spq_debug_reload_switches")
+    if hasattr(load(), "spq_debug_reload_switches"):
+        check(load().spq_debug_reload_switches(), "spq_debug_reload_switches")
 
 
 def check(rc, what):

@@ -1264,7 +1264,7 @@ constexpr int T128_LDS = T128_DEFER ? T128_STAGE : T128_STAGE + 4 * EPI_WAVE;
 // LV = 1: the store also writes the next layer's level matrix (GemmF16Args::lv): q = clamp(rint(o / s[n]), +-qhi) of the very
 // value o it stores -- IEEE division, round half to even, as quantization_methods.py:14-15 -- four fp16 levels (8 B) per lane
 // next to (or, with g.y null, instead of) the 16 B of fp32.
-template <int AL, int EPI, int LV = 0, bool SK = false>   // SK: the split-K form (plain epilogue only: EPI = LV = 0)
+template <int AL, int EPI, int LV = 0, bool SK = false, bool RAG = false>   // SK: the split-K form; RAG: N % 4 != 0 (scalar stores); both with the plain epilogue only (EPI = LV = 0)
 __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
   int sk_h = 0, tile = p;
   int t_lo = 0, t_hi = T;
   auto unit_of = [&](int u) {
-    sk_h = u / nwg; tile = u - sk_h * nwg;
+    sk_h = SK ? u / nwg : 0; tile = u - sk_h * nwg;
     t_lo = 0; t_hi = T;
     if (SK && S > 1) {
       const int share = (T + S - 1) / S;
@@ -1560,7 +1560,7 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
         ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n);     // [Np]: padded
         if (AL == 2) { ep_rs[tn].x *= out_scale; ep_rs[tn].y *= out_scale; ep_rs[tn].z *= out_scale; ep_rs[tn].w *= out_scale; }
         if (g.bias) {
-          if (LV != 0 || (g.N & 3) == 0) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
+          if (!RAG) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n);
           else {                                             // [N], ragged tail
             ep_bv[tn].x = g.bias[n];
             if (n + 1 < g.N) ep_bv[tn].y = g.bias[n + 1];
@@ -1573,7 +1573,7 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
     {                                                        // epilogue
       char* eb = smem + (T128_DEFER ? 0 : T128_STAGE) + w * EPI_WAVE;     // T128_DEFER: inside the (now free) stage buffer
       const int c4 = (lane & 7) * 4;
-      const bool vecN = LV != 0 || (g.N & 3) == 0;           // else rows of y are not 16-B aligned: scalar stores (LV: N % 64 == 0)
+      constexpr bool vecN = !RAG;                           // RAG: rows of y are not 16-B aligned -> scalar stores
       const bool interior = (bm + 128 <= g.M) && (bn + GN <= g.N) && vecN;
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
@@ -1621,7 +1621,7 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
             if (T128_DIAG & 4) { if (o.x == 12345.f) *reinterpret_cast<float4*>(dst) = o; }   // (non-temporal stores: no change, 79.3 vs 79.2 us)
             else if (interior) *reinterpret_cast<float4*>(dst) = o;
             else if (n_ok && m < g.M) {
-              if (vecN) *reinterpret_cast<float4*>(dst) = o;
+              if constexpr (vecN) *reinterpret_cast<float4*>(dst) = o;
               else {
                 dst[0] = o.x;
                 if (n + 1 < g.N) dst[1] = o.y;
@@ -1903,7 +1903,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   // split-K of the contraction (f16 limb kernels): decided here because the activation launch zeroes its counters
   int sk = 1;
   const int64_t sk_nwg = (L.Mp / 128) * (P.Np / GN);
-  if (!i8nl && do_gemm && a->epilogue == SPQ_EPILOGUE_NONE && !a->out_levels) {
+  if (!i8nl && do_gemm && a->epilogue == SPQ_EPILOGUE_NONE && !a->out_levels && (a->N & 3) == 0) {
     const int nl = lora_up ? (int)(L.Rp / GK) * 2 : 0;
     const int T = nl + (x3 ? 2 : 1) * (int)(L.Kp / GK);
     sk = t128_split(sk_nwg, T, nl, (int64_t)T128_WGS * gemm_grid(1 << 30), sw.split_k);
@@ -2064,6 +2064,8 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
 #undef SPQ_T128_ATTR
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<1, 0, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_f16x2_t128_kernel<2, 0, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
   }
   g.split = sk; g.sk_cnt = (int*)(ws + L.off_skcnt); g.sk_part = (float*)(ws + L.off_skpart);
   if (sk > 1 && !sk_zeroed && hipMemsetAsync(g.sk_cnt, 0, (size_t)(2 * sk_nwg) * sizeof(int), st) != hipSuccess) {
@@ -2074,6 +2076,8 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   // live in tools/variants/gemm_256x128.h (measured slower at every shape of SURVEY 8(d): config 3 1.466 -> 1.356 ms, config 5
   // 27.8 -> 27.4 ms)
   const bool gelu = a->epilogue == SPQ_EPILOGUE_GELU;
+  const bool ragged = (a->N & 3) != 0;                     // rows of y not 16-B aligned: the scalar-store instantiation (plain epilogue)
+  if (ragged && (gelu || g.lv)) { set_error("spq_linear_lora_fwd: the fused GELU / levels-out epilogues need N %% 4 == 0 (got N=%lld)", (long long)a->N); return SPQ_ERR_UNSUPPORTED; }
   const int ntiles = 2 * g.tiles_m * g.tiles_n * sk;
   const unsigned cus3 = (sk > 1 ? 2 : 1) * T128_WGS * gemm_grid(1 << 30);    // split-K: one unit per workgroup
   const unsigned grid128 = (unsigned)ntiles < cus3 ? (unsigned)ntiles : cus3;
@@ -2082,6 +2086,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
                                else if (gelu) SPQ_T128_LAUNCH(1, 1, LV); else SPQ_T128_LAUNCH(1, 0, LV); } while (0)
   if (g.lv && g.lv_lo) SPQ_T128_PICK(2);
   else if (g.lv) SPQ_T128_PICK(1);
+  else if (ragged) { if (x3) gemm_f16x2_t128_kernel<2, 0, 0, false, true><<<grid128, 256, T128_LDS, st>>>(g); else gemm_f16x2_t128_kernel<1, 0, 0, false, true><<<grid128, 256, T128_LDS, st>>>(g); }
   else if (sk > 1) { if (x3) gemm_f16x2_t128_kernel<2, 0, 0, true><<<grid128, 256, T128_LDS, st>>>(g); else gemm_f16x2_t128_kernel<1, 0, 0, true><<<grid128, 256, T128_LDS, st>>>(g); }
   else SPQ_T128_PICK(0);
 #undef SPQ_T128_PICK
