@@ -38,7 +38,9 @@ FLOP_PER_STEP = 2 * M_TOKENS * K_IN * N_OUT + 2 * M_TOKENS * K_IN * RANK + 2 * M
 BYTES_PER_STEP = 4 * (M_TOKENS * K_IN + N_OUT * K_IN + K_IN * RANK + RANK * N_OUT + N_OUT + M_TOKENS * N_OUT) \
     + 4 * (K_IN + N_OUT + RANK + N_OUT)                                                                        # ~136.29 MB
 PEAK = {"f32": 157.3, "f16": 2500.0, "i8": 5000.0, "hbm_gbs": 8000.0}   # MI355X_MICROARCH.md: dense MFMA TFLOP/s, HBM GB/s
-SETUP_STEPS = 200         # untimed, before the W warm-ups: grows the workspaces and lets the clocks settle (~25 ms; not part of W or K)
+SETUP_STEPS = 2000        # untimed, before the W warm-ups: grows the workspaces and lets the clocks settle (~0.2 s; not part of W or K).
+                          # Measured (tools/setup_steps_ab.sh, one box, --steps 20 --warmup 5): 200 -> 0.0994 / 0.1016 / 0.1013 ms per step in the
+                          # first timed region, 2000 -> 0.0963 / 0.0965: after 20 ms of work the chip has not reached the clock it then holds.
 STAT_REPEATS = 5          # extra repetitions of the K-step region for the median / min figure
 
 
@@ -93,13 +95,16 @@ class HipEvents:
 
     def __init__(self, n):
         self.hip = ctypes.CDLL("libamdhip64.so")
-        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
         self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
         self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
         self.pairs = []
         for _ in range(n):
             b, e = ctypes.c_void_p(), ctypes.c_void_p()
-            assert self.hip.hipEventCreate(ctypes.byref(b)) == 0 and self.hip.hipEventCreate(ctypes.byref(e)) == 0
+            # hipEventDisableSystemFence: the record is a timestamp marker on the stream without the system-scope cache release a
+            # default event carries (nothing on the host reads data the kernel wrote; only the two timestamps are compared)
+            flags = 0x20000000
+            assert self.hip.hipEventCreateWithFlags(ctypes.byref(b), flags) == 0 and self.hip.hipEventCreateWithFlags(ctypes.byref(e), flags) == 0
             self.pairs.append((b, e))
 
     def elapsed_ms(self):
