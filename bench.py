@@ -399,7 +399,7 @@ def main():
             except Exception:
                 traffic = None
         kernel_name = ("gemm_i8_k128_kernel (dense contraction on v_mfma_i32_32x32x32_i8 + LoRA-up on f16 limbs + bias)" if is_i8 else
-                       "gemm_f16x2_t128 / gemm_f16x2_s16 (dense contraction + LoRA-up + bias, v_mfma_f32_16x16x32_f16)" if is_f16
+                       "gemm_f16x2_t128_kernel (dense contraction + LoRA-up + bias, v_mfma_f32_16x16x32_f16)" if is_f16
                        else "gemm_f32_nt (dense contraction + LoRA-up + bias)")
         dtype_s = ("i8 (int8 levels x int8 weight levels, i32 accumulate: exact)" if is_i8 else
                    "f16x2-limb operands, f32 accumulate (fp32-accurate)" if is_f16 else "f32")

@@ -397,7 +397,7 @@ class SPLinearWithLoRA(nn.Module):
             nw, nb = norm.weights[str(norm.current_precision)], norm.biases[str(norm.current_precision)]
             a.ln_weight, a.ln_bias, a.ln_eps = nw.data_ptr(), nb.data_ptr(), float(norm.eps)
             self._norm_fused = True
-        if activation == 'gelu' and prep.path in (_lib.PATH_F16X2, _lib.PATH_F16X3, _lib.PATH_I8) and N % 4 == 0:
+        if activation == 'gelu' and (prep.path == _lib.PATH_I8 or (prep.path in (_lib.PATH_F16X2, _lib.PATH_F16X3) and N % 4 == 0)):
             a.epilogue = _lib.EPILOGUE_GELU
             self._activation_fused = True
         with _lib.on_device(x.device):

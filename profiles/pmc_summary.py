@@ -5,7 +5,7 @@ root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0][-40:]
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "").strip()[-60:]
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     if not any(s in k for s in ("gemm", "xpass", "prep", "fakequant")):

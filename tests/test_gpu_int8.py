@@ -104,5 +104,6 @@ def test_int8_path_against_oracle(pkg, shape):
             assert_close_y(outs[pname], y_ref, f"{pname} {shape}", 1e-5)
         assert torch.equal(outs["auto"], outs["i8"])
         y_gelu = layer(x1.to(DEV), activation="gelu")               # the GELU epilogue of the int8 kernels
-        assert layer._activation_fused
+        # (fp16-level paths fuse the GELU when rows of y are 16-B aligned; the ragged-N instantiation has the plain epilogue only)
+        assert layer._activation_fused == (layer._last_path == pkg._lib.PATH_I8 or N % 4 == 0)
     assert_close_y(y_gelu, torch.nn.functional.gelu(y_ref), f"gelu {shape}", 1e-5)
