@@ -28,7 +28,7 @@ int launch_gemm_f32_nt(const float* A, int64_t lda, const float* B, int64_t ldb,
                        int64_t lda2, const float* B2, int64_t ldb2, int64_t K2, float alpha2,
                        const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, hipStream_t st);
 int fwd_f16x2(const spq_fwd_args* a, hipStream_t st);
-size_t fwd_f16x2_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r);
+size_t fwd_f16x2_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path);
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -61,7 +61,7 @@ extern "C" int spq_device_arch(char* buf, int buflen) {
 extern "C" size_t spq_fwd_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path) {
   if (M <= 0 || K <= 0 || N <= 0 || r < 0) return 0;
   if (path == SPQ_PATH_F16X2 || path == SPQ_PATH_U8X2 || path == SPQ_PATH_F16X3 || path == SPQ_PATH_I8)
-    return fwd_f16x2_workspace_bytes(M, K, N, r);
+    return fwd_f16x2_workspace_bytes(M, K, N, r, path);
   // F32 path: fake-quantised activations [M,K] + low-rank intermediate [M,r]
   return align_up((size_t)M * K * sizeof(float), 256) + align_up((size_t)M * (size_t)r * sizeof(float), 256) + 256;
 }

@@ -72,13 +72,23 @@ static int t128_split(int64_t nwg, int T, int nl, int64_t slots, int forced) {
   }
   return best;
 }
-constexpr int SK_MAX_UNITS = 2 * 3 * 512;        // workspace bound: units <= 2 x slots, slots <= 3 x 512 CUs
-static int64_t sk_reserve_units(int64_t M, int64_t N) {
+unsigned gemm_grid(int ntiles);
+int split_k_switch();
+// units (workgroups) of the split-K form to reserve scratch for: the largest split the forward could take for this shape under the
+// current SPQ_SPLIT_K, over both activation-limb counts and with / without LoRA stages (the workspace is sized before those are known)
+static int64_t sk_reserve_units(int64_t M, int64_t K, int64_t N, int64_t r, int al_only) {   // al_only: 1 / 2 activation limbs, 0 = either
   const int64_t nwg = (pad_to(M, 256) / 128) * (pad_to(N, 128) / 128);
-  return nwg >= 3 * 512 ? 0 : std::min<int64_t>(4 * nwg, SK_MAX_UNITS);
+  const int64_t slots = 3 * (int64_t)gemm_grid(1 << 30);
+  const int forced = split_k_switch();
+  if (al_only < 0) return 0;                               // (the int8 kernels have no split-K form)
+  const int kb = (int)(pad_to(K, 64) / 64), nlr = r > 0 ? (int)(pad_to(r, 64) / 64) * 2 : 0;
+  int S = 1;
+  for (int al = (al_only ? al_only : 1); al <= (al_only ? al_only : 2); ++al)
+    for (int nl : {0, nlr}) S = std::max(S, t128_split(nwg, nl + al * kb, nl, slots, forced));
+  return S > 1 ? nwg * S : 0;
 }
 
-static F16x2Layout make_layout(int64_t M, int64_t K, int64_t r, int64_t N = 0) {
+static F16x2Layout make_layout(int64_t M, int64_t K, int64_t r, int64_t N = 0, int al = 0) {
   F16x2Layout L;
   L.Mp = pad_to(M, GM); L.Kp = pad_to(K, GK); L.Rp = r > 0 ? pad_to(r, GK) : 0;
   size_t o = 0;
@@ -88,14 +98,16 @@ static F16x2Layout make_layout(int64_t M, int64_t K, int64_t r, int64_t N = 0) {
   L.off_tlo = o; o += pad_to((size_t)L.Mp * L.Rp * 2, 256);
   L.off_rowinv = o; o += pad_to((size_t)L.Mp * 4, 256);
   // split-K scratch: {tickets, done} per tile, then one 64-KB register image per unit (N = 0: a layout without it)
-  const int64_t sku = N > 0 ? sk_reserve_units(M, N) : 0;
+  const int64_t sku = N > 0 ? sk_reserve_units(M, K, N, r, al) : 0;
   L.off_skcnt = o; o += sku ? 8192 : 0;
   L.off_skpart = o; o += (size_t)sku * 65536;
   L.total = o + 256;
   return L;
 }
 
-size_t fwd_f16x2_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r) { return make_layout(M, K, r, N).total; }
+size_t fwd_f16x2_workspace_bytes(int64_t M, int64_t K, int64_t N, int64_t r, int path) {
+  return make_layout(M, K, r, N, path == SPQ_PATH_F16X3 ? 2 : path == SPQ_PATH_I8 ? -1 : 1).total;
+}
 
 // power of two p with  v_max * p  in [2^13, 2^14)   (p = 1 for v_max == 0 or non-finite)
 __device__ __forceinline__ float pow2_scale_for(float vmax) {
@@ -1832,6 +1844,7 @@ static Switches read_switches() {
 }
 static Switches g_switches = read_switches();
 extern "C" int spq_debug_reload_switches(void) { g_switches = read_switches(); return SPQ_OK; }
+int split_k_switch() { return g_switches.split_k; }
 
 int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   const bool x3 = a->path == SPQ_PATH_F16X3;
@@ -1859,7 +1872,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     return SPQ_ERR_UNSUPPORTED;
   }
   SPQ_REQUIRE(a->w_rowscale, "spq_linear_lora_fwd: w_rowscale missing for SPQ_PATH_F16X2");
-  const F16x2Layout L = make_layout(a->M, a->K, a->r, a->N);
+  const F16x2Layout L = make_layout(a->M, a->K, a->r, a->N, x3 ? 2 : i8nl ? -1 : 1);
   const PrepLayout P = make_prep_layout(a->N, a->K, a->r);
   char* ws = (char*)a->workspace;
   const char* wp = (const char*)a->w_prep;
@@ -1907,7 +1920,7 @@ int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
     const int nl = lora_up ? (int)(L.Rp / GK) * 2 : 0;
     const int T = nl + (x3 ? 2 : 1) * (int)(L.Kp / GK);
     sk = t128_split(sk_nwg, T, nl, (int64_t)T128_WGS * gemm_grid(1 << 30), sw.split_k);
-    if (sk > 1 && sk_nwg * sk > sk_reserve_units(a->M, a->N)) sk = 1;
+    if (sk > 1 && sk_nwg * sk > sk_reserve_units(a->M, a->K, a->N, a->r, x3 ? 2 : 1)) sk = 1;   // (cannot happen: the reserve is the maximum over the cases)
   }
   bool sk_zeroed = false;
   x.zero_ptr = nullptr; x.zero_n = 0;
