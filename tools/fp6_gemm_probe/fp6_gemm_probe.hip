@@ -220,6 +220,15 @@ __global__ __launch_bounds__(256, FP6_WGS) void gemm_fp6_t128_kernel(GemmFp6Args
 #ifndef RING_NS
 #define RING_NS 11
 #endif
+#ifndef RING_ONESET
+#define RING_ONESET 0
+#endif
+#ifndef RING_HYST
+#define RING_HYST 3
+#endif
+#ifndef RING_SLEEP     // s_sleep argument inside a waiting loop (0: tight polling)
+#define RING_SLEEP 0
+#endif
 #ifndef RING_DIAG     // timing probes (wrong results): 1 no copies, 2 no MFMAs, 4 no fragment reads, 8 loader waves at top issue priority, 16 no stores, 32 no waiting on either side
 #define RING_DIAG 0
 #endif
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
     int spins = 0;
     while (known < need && !timed_out && !(RING_DIAG & 32)) {
       known = min_line(addr, words);
-      if (known < need) { if (++spins > (1 << 20)) timed_out = true; }
+      if (known < need) { if (RING_SLEEP) __builtin_amdgcn_s_sleep(RING_SLEEP); if (++spins > (1 << 20)) timed_out = true; }
     }
   };
   auto publish = [&](unsigned addr, int value) { if (lane == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(value) : "memory"); };
@@ -300,7 +309,10 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
         if (released < gi - RING_NS + 1) {                                     // blocked: confirm everything issued so far instead of idling behind the look-ahead
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           publish(fullv + 4u * (unsigned)lw, gi);
-          wait_for(released, gi - RING_NS + 1, freev, 8);
+          // hysteresis: wait for RING_HYST more releases than needed, so that the next items go out without a poll each (the compute
+          // waves can release up to item gi - 3 on what is published: RING_HYST <= RING_NS - 4 cannot deadlock)
+          wait_for(released, min(gi - RING_NS + 1 + RING_HYST, total_items - RING_NS), freev, 8);
+          if (released < gi - RING_NS + 1) wait_for(released, gi - RING_NS + 1, freev, 8);
         }
       }
       const unsigned char* src = it < 2 ? g.A6 + ((int64_t)(bm / 32 + 4 * it + lw) * KB + kb) * F6_PAIR
@@ -384,6 +396,11 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
             acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[tm], fb[tn], acc[tm][tn], 2, 2, 0, 127, 0, sb);
         __builtin_amdgcn_sched_barrier(0);
       };
+#if RING_ONESET          // one fragment set: 24 registers fewer; the SIMD's other compute wave covers the read latency
+      for (int pl = 0; pl < 5; ++pl) { load_plane(b0, pl); mfma_plane(b0, pl); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      publish(freev + 4u * (unsigned)w, gi + 7);
+#else
       load_plane(b0, 0);
       load_plane(b1, 1); mfma_plane(b0, 0);
       load_plane(b0, 2); mfma_plane(b1, 1);
@@ -392,6 +409,7 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       publish(freev + 4u * (unsigned)w, gi + 7);
       mfma_plane(b0, 4);
+#endif
       gi += 7;
     }
     // epilogue (the production one) through this wave's own slice
