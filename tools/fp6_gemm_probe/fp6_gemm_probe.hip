@@ -241,7 +241,7 @@ constexpr int RING_CNT_OFF = RING_EPI_OFF + 8 * EPI_WAVE;        // FULL[NS], FR
 constexpr int RING_LDS = RING_CNT_OFF + 64;
 static_assert(RING_LDS <= 160 * 1024, "LDS");
 static_assert(FP6_NL == 5, "the ring kernel is written for five digit planes");
-struct GemmFp6RingArgs { GemmFp6Args f; int* err; };
+struct GemmFp6RingArgs { GemmFp6Args f; int* err; unsigned long long* stamps; };
 
 __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs ga) {
   const GemmFp6Args& g = ga.f;
@@ -301,29 +301,43 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
     auto glds = [&](const unsigned char* sbase, unsigned lds_addr) {
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
     };
+    // Seven running source pointers (A rows 0..127 / 128..255 and the five planes of the tile's columns), + 3 KB per k block: the
+    // loader's scalar stream shares its SIMD with two MFMA-streaming waves and a per-item address computation (64-bit multiplies)
+    // cost ~250 cycles per item -- stamped: the compute waves spent a third of their time waiting for items even with NO copies.
     int released = 0;
-    for (int gi = 0; gi < total_items; ++gi) {
-      const int slot = gi % RING_NS;
-      if (gi >= RING_NS && released < gi - RING_NS + 1) {                     // every compute wave must be done with the item this slot held
-        released = min_line(freev, 8);
-        if (released < gi - RING_NS + 1) {                                     // blocked: confirm everything issued so far instead of idling behind the look-ahead
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          publish(fullv + 4u * (unsigned)lw, gi);
-          // hysteresis: wait for RING_HYST more releases than needed, so that the next items go out without a poll each (the compute
-          // waves can release up to item gi - 3 on what is published: RING_HYST <= RING_NS - 4 cannot deadlock)
-          wait_for(released, min(gi - RING_NS + 1 + RING_HYST, total_items - RING_NS), freev, 8);
-          if (released < gi - RING_NS + 1) wait_for(released, gi - RING_NS + 1, freev, 8);
+    const unsigned char* src[7];
+    auto set_tile = [&]() {
+      src[0] = g.A6 + ((int64_t)(bm / 32 + lw) * KB) * F6_PAIR;
+      src[1] = g.A6 + ((int64_t)(bm / 32 + 4 + lw) * KB) * F6_PAIR;
+#pragma unroll
+      for (int pl = 0; pl < 5; ++pl) src[2 + pl] = g.W6 + (int64_t)pl * plane_stride + ((int64_t)(bn / 32 + lw) * KB) * F6_PAIR;
+    };
+    set_tile();
+    int gi = 0, slot = 0;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+      for (kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (it = 0; it < 7; ++it) {
+          if (gi >= RING_NS && released < gi - RING_NS + 1) {                     // every compute wave must be done with the item this slot held
+            released = min_line(freev, 8);
+            if (released < gi - RING_NS + 1) {                                     // blocked: confirm everything issued so far instead of idling behind the look-ahead
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              publish(fullv + 4u * (unsigned)lw, gi);
+              wait_for(released, gi - RING_NS + 1, freev, 8);
+            }
+          }
+          const unsigned dst = lds0 + (unsigned)slot * RING_ITEM + (unsigned)(3 * lw) * 1024u;
+          if (!(RING_DIAG & 1)) { glds(src[it], dst); glds(src[it] + 1024, dst + 1024u); glds(src[it] + 2048, dst + 2048u); }
+          src[it] += F6_PAIR;
+          if (gi >= RING_LOOK) {                                                    // item gi - LOOK has landed once only the younger 3 LOOK copies are in flight
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * RING_LOOK) : "memory");
+            publish(fullv + 4u * (unsigned)lw, gi - RING_LOOK + 1);
+          }
+          ++gi; slot = slot == RING_NS - 1 ? 0 : slot + 1;
         }
       }
-      const unsigned char* src = it < 2 ? g.A6 + ((int64_t)(bm / 32 + 4 * it + lw) * KB + kb) * F6_PAIR
-                                        : g.W6 + (int64_t)(it - 2) * plane_stride + ((int64_t)(bn / 32 + lw) * KB + kb) * F6_PAIR;
-      const unsigned dst = lds0 + (unsigned)slot * RING_ITEM + (unsigned)(3 * lw) * 1024u;
-      if (!(RING_DIAG & 1)) { glds(src, dst); glds(src + 1024, dst + 1024u); glds(src + 2048, dst + 2048u); }
-      if (gi >= RING_LOOK) {                                        // item gi - LOOK has landed once only the younger 3 LOOK copies are in flight
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * RING_LOOK) : "memory");
-        publish(fullv + 4u * (unsigned)lw, gi - RING_LOOK + 1);
-      }
-      if (++it == 7) { it = 0; if (++kb == KB) { kb = 0; p += gstride; if (p < nwg) tile_of(p, bm, bn); } }
+      p += gstride;
+      if (p < nwg) { tile_of(p, bm, bn); set_tile(); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the last LOOK items
     publish(fullv + 4u * (unsigned)lw, total_items);
@@ -343,6 +357,9 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
   };
   f32x4 acc[4][4];
   int gi = 0, ready = 0, dummy = 0;
+  unsigned long long st[6] = {0, 0, 0, 0, 0, 0};      // RING_DIAG & 256: cycles in [0] waiting for items, [1] fragment reads landing, [2] MFMA issue, [3] epilogue, [4] total
+#define RSTAMP() ((RING_DIAG & 256) ? __builtin_readcyclecounter() : 0ull)
+  const unsigned long long t_begin = RSTAMP();
   v8i kc[8];
   for (int i = 0; i < 8; ++i) for (int e = 0; e < 8; ++e) kc[i][e] = 0x08208208 + lane + i;
   int p = blockIdx.x;
@@ -361,21 +378,28 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
       // my A item (the other half is released implicitly by the progress word of the first plane)
       {
         const int slot = (gi + my_half) % RING_NS;
+        const unsigned long long s0 = RSTAMP();
         wait_for(ready, gi + my_half + 1, fullv, 4);
+        st[0] += RSTAMP() - s0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) if (!(RING_DIAG & 4)) fa[t] = frag((unsigned)slot * RING_ITEM, 4 * (wm & 1) + t);
       }
       auto load_plane = [&](v8i (&fb)[4], int pl) {               // wait for the plane, read it; publish the previous item once ITS reads are in registers
         const int item = gi + 2 + pl, slot = item % RING_NS;
+        const unsigned long long s0 = RSTAMP();
         wait_for(ready, item + 1, fullv, 4);
+        const unsigned long long s1 = RSTAMP();
+        st[0] += s1 - s0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) if (!(RING_DIAG & 4)) fb[t] = frag((unsigned)slot * RING_ITEM, 4 * wn + t);
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");        // everything older than this plane's eight reads has landed
         publish(freev + 4u * (unsigned)w, item);                   // items 0 .. item - 1 are released
+        if (RING_DIAG & 256) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st[1] += RSTAMP() - s1; }
       };
       auto mfma_plane = [&](const v8i (&fb)[4], int pl) {
         const int sb = 127 + 3 + 5 * pl;
         if (RING_DIAG & 2) return;
+        const unsigned long long m0 = RSTAMP();
         if (RING_DIAG & 128) {                                     // probe: the MFMAs on CONSTANT registers, the loaded fragments only folded into a VALU sum
           int x = 0;
 #pragma unroll
@@ -395,6 +419,7 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
           for (int tn = 0; tn < 4; ++tn)
             acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[tm], fb[tn], acc[tm][tn], 2, 2, 0, 127, 0, sb);
         __builtin_amdgcn_sched_barrier(0);
+        if (RING_DIAG & 256) st[2] += RSTAMP() - m0;
       };
 #if RING_ONESET          // one fragment set: 24 registers fewer; the SIMD's other compute wave covers the read latency
       for (int pl = 0; pl < 5; ++pl) { load_plane(b0, pl); mfma_plane(b0, pl); }
@@ -413,6 +438,7 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
       gi += 7;
     }
     // epilogue (the production one) through this wave's own slice
+    const unsigned long long e0 = RSTAMP();
     float4 ep_rs[2], ep_bv[2];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
@@ -444,6 +470,11 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
         }
       }
     }
+    st[3] += RSTAMP() - e0;
+  }
+  if ((RING_DIAG & 256) && lane == 0 && ga.stamps) {
+    st[4] = RSTAMP() - t_begin;
+    for (int i = 0; i < 5; ++i) ga.stamps[((size_t)blockIdx.x * 8 + w) * 8 + i] = st[i];
   }
   if ((timed_out || dummy == 0x7fffffff) && lane == 0) atomicAdd(ga.err, 1);
 }
@@ -497,6 +528,7 @@ int main() {      // timing of the ring kernel alone on random operand bytes (ev
   hipMemset(rs, 0, N * 4); hipMemset(bias, 0, N * 4); hipMemset(derr, 0, 4);
   GemmFp6RingArgs fr{}; fr.f.A6 = dA; fr.f.W6 = dW; fr.f.rowscale = rs; fr.f.bias = bias; fr.f.y = y; fr.f.M = M; fr.f.N = N; fr.f.K = K;
   fr.f.tiles_m = M / 128; fr.f.tiles_n = N / 128; fr.err = derr;
+  unsigned long long* dst = nullptr; hipMalloc(&dst, 256 * 8 * 8 * 8); hipMemset(dst, 0, 256 * 8 * 8 * 8); fr.stamps = dst;
   hipFuncSetAttribute((const void*)gemm_fp6_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
   const unsigned gridr = std::min<unsigned>((M / 256) * (N / 128), gemm_grid(1 << 30));
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -506,6 +538,14 @@ int main() {      // timing of the ring kernel alone on random operand bytes (ev
     hipEventRecord(a); for (int i = 0; i < 200; ++i) gemm_fp6_ring_kernel<<<gridr, 768, RING_LDS>>>(fr); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
     int herr = 0; hipMemcpy(&herr, derr, 4, hipMemcpyDeviceToHost);
     printf("ring NS=%d LOOK=%d DIAG=%d: %.1f us (%d time-outs)\n", RING_NS, RING_LOOK, RING_DIAG, ms * 5.f, herr);
+  }
+  if (RING_DIAG & 256) {
+    std::vector<unsigned long long> h(256 * 8 * 8); hipMemcpy(h.data(), dst, h.size() * 8, hipMemcpyDeviceToHost);
+    double sum[5] = {0, 0, 0, 0, 0};
+    for (unsigned b = 0; b < gridr; ++b) for (int w = 0; w < 8; ++w) for (int i = 0; i < 5; ++i) sum[i] += (double)h[((size_t)b * 8 + w) * 8 + i];
+    const double nw = gridr * 8.0;
+    printf("compute waves, counter cycles per wave (18 k blocks, 3 tiles): waiting for items %.0f | fragment reads landing %.0f | MFMA issue %.0f | epilogue %.0f | total %.0f\n",
+           sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw);
   }
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -585,7 +625,7 @@ int main(int argc, char** argv) {
   // ---- the ring form
   float* y6r; hipMalloc(&y6r, (size_t)M * N * 4); hipMemset(y6r, 0, (size_t)M * N * 4);
   int* derr; hipMalloc(&derr, 4); hipMemset(derr, 0, 4);
-  GemmFp6RingArgs fr{f, derr}; fr.f.y = y6r;
+  GemmFp6RingArgs fr{f, derr, nullptr}; fr.f.y = y6r;
   hipFuncSetAttribute((const void*)gemm_fp6_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS);
   const unsigned gridr = std::min<unsigned>((M / 256) * (N / 128), cus);
   gemm_fp6_ring_kernel<<<gridr, 768, RING_LDS>>>(fr);
