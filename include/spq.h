@@ -67,6 +67,9 @@ typedef void* spq_stream_t;
 int spq_version(void);
 /* Re-read the SPQ_* tuning switches from the environment (they are read once, at the first call; tests flip them in-process). */
 int spq_debug_reload_switches(void);
+/* Host logic only (no launch): the number of workgroups that would share one 128 x 128 tile's k range in the contraction of this
+ * shape (1 = no split), under the current SPQ_SPLIT_K switch; DESIGN.md 3.3a. */
+int spq_debug_split_k(int64_t M, int64_t K, int64_t N, int64_t r, int path);
 const char* spq_last_error(void);
 /* Writes the gcnArchName of the current device ("gfx950:sramecc+:xnack-") into buf. */
 int spq_device_arch(char* buf, int buflen);

@@ -71,6 +71,7 @@ SIGNATURES = {
                                 _p, _int, _int, _p, _sz, _p, _p, _p, _p, _p, _p]),
     "spq_layernorm": (_int, [_p, _i64, _i64, _p, _p, _f, _p, _p]),
     "spq_debug_reload_switches": (_int, []),
+    "spq_debug_split_k": (_int, [_i64, _i64, _i64, _i64, _int]),
     "spq_version": (_int, []),
     "spq_last_error": (C.c_char_p, []),
     "spq_device_arch": (_int, [C.c_char_p, _int]),

@@ -1845,6 +1845,14 @@ static Switches read_switches() {
 static Switches g_switches = read_switches();
 extern "C" int spq_debug_reload_switches(void) { g_switches = read_switches(); return SPQ_OK; }
 int split_k_switch() { return g_switches.split_k; }
+// host logic, no launch: how many units per tile the forward would use for this shape under the current switches (CPU-tested)
+extern "C" int spq_debug_split_k(int64_t M, int64_t K, int64_t N, int64_t r, int path) {
+  if (M <= 0 || K <= 0 || N <= 0 || r < 0 || (path != SPQ_PATH_F16X2 && path != SPQ_PATH_F16X3) || (N & 3) != 0) return 1;
+  const int64_t nwg = (pad_to(M, 256) / 128) * (pad_to(N, 128) / 128);
+  const int nl = r > 0 ? (int)(pad_to(r, 64) / 64) * 2 : 0;
+  const int T = nl + (path == SPQ_PATH_F16X3 ? 2 : 1) * (int)(pad_to(K, 64) / 64);
+  return t128_split(nwg, T, nl, (int64_t)T128_WGS * gemm_grid(1 << 30), g_switches.split_k);
+}
 
 int fwd_f16x2(const spq_fwd_args* a, hipStream_t st) {
   const bool x3 = a->path == SPQ_PATH_F16X3;
