@@ -352,6 +352,9 @@ __global__ __launch_bounds__(512, 4) void gemm_fp6_w8_kernel(GemmFp6Args g) {
 #ifndef RING_HYST
 #define RING_HYST 3
 #endif
+#ifndef RING_AREG      // 1: the activation fragments go global -> registers in the compute waves; the ring carries the digit planes only
+#define RING_AREG 0
+#endif
 #ifndef RING_SLEEP     // s_sleep argument inside a waiting loop (0: tight polling)
 #define RING_SLEEP 0
 #endif
@@ -414,7 +417,8 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
   };
   auto publish = [&](unsigned addr, int value) { if (lane == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(value) : "memory"); };
   const int my_tiles = (nwg - (int)blockIdx.x + gstride - 1) / gstride;   // tiles this workgroup walks
-  const int total_items = my_tiles * KB * 7;
+  constexpr int IPK = RING_AREG ? 5 : 7;                          // items per k block (RING_AREG: the A fragments go global -> registers, not through the ring)
+  const int total_items = my_tiles * KB * IPK;
 
   if (w >= 8) {
     // ================================================== loader ==================================================
@@ -433,17 +437,20 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
     int released = 0;
     const unsigned char* src[7];
     auto set_tile = [&]() {
-      src[0] = g.A6 + ((int64_t)(bm / 32 + lw) * KB) * F6_PAIR;
-      src[1] = g.A6 + ((int64_t)(bm / 32 + 4 + lw) * KB) * F6_PAIR;
+      if (!RING_AREG) {
+        src[5] = g.A6 + ((int64_t)(bm / 32 + lw) * KB) * F6_PAIR;
+        src[6] = g.A6 + ((int64_t)(bm / 32 + 4 + lw) * KB) * F6_PAIR;
+      }
 #pragma unroll
-      for (int pl = 0; pl < 5; ++pl) src[2 + pl] = g.W6 + (int64_t)pl * plane_stride + ((int64_t)(bn / 32 + lw) * KB) * F6_PAIR;
+      for (int pl = 0; pl < 5; ++pl) src[pl] = g.W6 + (int64_t)pl * plane_stride + ((int64_t)(bn / 32 + lw) * KB) * F6_PAIR;
     };
     set_tile();
     int gi = 0, slot = 0;
     for (int ti = 0; ti < my_tiles; ++ti) {
       for (kb = 0; kb < KB; ++kb) {
 #pragma unroll
-        for (it = 0; it < 7; ++it) {
+        for (int it7 = 0; it7 < IPK; ++it7) {
+          it = RING_AREG ? it7 : (it7 < 2 ? 5 + it7 : it7 - 2);               // item order: (A half 0, A half 1,) planes 0..4
           if (gi >= RING_NS && released < gi - RING_NS + 1) {                     // every compute wave must be done with the item this slot held
             released = min_line(freev, 8);
             if (released < gi - RING_NS + 1) {                                     // blocked: confirm everything issued so far instead of idling behind the look-ahead
@@ -501,8 +508,16 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
     for (int kb = 0; kb < KB; ++kb) {
       v8i fa[4], b0[4], b1[4];
       if (RING_DIAG & 4) { for (int t = 0; t < 4; ++t) for (int e = 0; e < 8; ++e) { fa[t][e] = lane + e; b0[t][e] = lane * 3 + e; b1[t][e] = lane * 5 + e; } }
-      // my A item (the other half is released implicitly by the progress word of the first plane)
-      {
+      if (RING_AREG) {                                             // A fragments: straight from global memory (operand-tile order: 16 B + 8 B per lane)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int rec = 4 * wm + t;
+          const unsigned char* pb = g.A6 + ((int64_t)(bm / 32 + (rec >> 1)) * KB + kb) * F6_PAIR;
+          const uint4 a = *reinterpret_cast<const uint4*>(pb + (rec & 1) * 1024 + lane * 16);
+          const uint2 b = *reinterpret_cast<const uint2*>(pb + 2048 + (rec & 1) * 512 + lane * 8);
+          fa[t][0] = (int)a.x; fa[t][1] = (int)a.y; fa[t][2] = (int)a.z; fa[t][3] = (int)a.w; fa[t][4] = (int)b.x; fa[t][5] = (int)b.y; fa[t][6] = 0; fa[t][7] = 0;
+        }
+      } else {       // my A item (the other half is released implicitly by the progress word of the first plane)
         const int slot = (gi + my_half) % RING_NS;
         const unsigned long long s0 = RSTAMP();
         wait_for(ready, gi + my_half + 1, fullv, 4);
@@ -511,7 +526,7 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
         for (int t = 0; t < 4; ++t) if (!(RING_DIAG & 4)) fa[t] = frag((unsigned)slot * RING_ITEM, 4 * (wm & 1) + t);
       }
       auto load_plane = [&](v8i (&fb)[4], int pl) {               // wait for the plane, read it; publish the previous item once ITS reads are in registers
-        const int item = gi + 2 + pl, slot = item % RING_NS;
+        const int item = gi + (RING_AREG ? 0 : 2) + pl, slot = item % RING_NS;
         const unsigned long long s0 = RSTAMP();
         wait_for(ready, item + 1, fullv, 4);
         const unsigned long long s1 = RSTAMP();
@@ -550,7 +565,7 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
 #if RING_ONESET          // one fragment set: 24 registers fewer; the SIMD's other compute wave covers the read latency
       for (int pl = 0; pl < 5; ++pl) { load_plane(b0, pl); mfma_plane(b0, pl); }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      publish(freev + 4u * (unsigned)w, gi + 7);
+      publish(freev + 4u * (unsigned)w, gi + IPK);
 #else
       load_plane(b0, 0);
       load_plane(b1, 1); mfma_plane(b0, 0);
@@ -558,10 +573,10 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
       load_plane(b1, 3); mfma_plane(b0, 2);
       load_plane(b0, 4); mfma_plane(b1, 3);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      publish(freev + 4u * (unsigned)w, gi + 7);
+      publish(freev + 4u * (unsigned)w, gi + IPK);
       mfma_plane(b0, 4);
 #endif
-      gi += 7;
+      gi += IPK;
     }
     // epilogue (the production one) through this wave's own slice
     const unsigned long long e0 = RSTAMP();
