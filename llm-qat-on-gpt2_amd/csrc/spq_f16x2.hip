@@ -1522,8 +1522,11 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
       if (tid == 0) {
         int spins = 0;
         while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S - 1 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(4);
+        tk[0] = spins >= (1 << 22);                          // (cannot happen by construction; if it ever does, the tile comes out NaN, not silently wrong)
       }
       __syncthreads();
+      const bool sk_lost = tk[0] != 0;
+      __syncthreads();                                      // (the epilogue writes its slices over tk)
       auto combine = [&](auto HALF) {                       // 8 accumulator blocks at a time: 32 registers of loads in flight
         constexpr int half = decltype(HALF)::value;
         f32x4 run[8];
@@ -1547,6 +1550,12 @@ __global__ __launch_bounds__(256, T128_WGS) void gemm_f16x2_t128_kernel(GemmF16A
       };
       combine(std::integral_constant<int, 0>{});
       combine(std::integral_constant<int, 1>{});
+      if (sk_lost) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i >> 2][i & 3][e] = __builtin_nanf("");
+      }
     }
     // epilogue operands: fetched here, not at the tile's start (16 registers that three waves per SIMD do not leave through
     // the stage loop); the CU's other workgroups cover the load's latency
