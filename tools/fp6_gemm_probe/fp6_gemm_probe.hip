@@ -335,6 +335,146 @@ __global__ __launch_bounds__(512, 4) void gemm_fp6_w8_kernel(GemmFp6Args g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The transplant on 128 x 64 tiles: 42 KB of LDS per workgroup (A 12 KB + five planes of 64 rows, 6 KB each), so THREE workgroups
+// share a CU as in the production kernel (12 waves: three per SIMD); 4 waves of 64 x 32 outputs.  More copy bytes (774 MB against 663)
+// for more overlap.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int N64_PLANE = 2 * F6_PAIR;                            // 64 rows x 128 k: 6 KB
+constexpr int N64_STAGE = F6_PLANE + FP6_NL * N64_PLANE;          // 42 KB
+__global__ __launch_bounds__(256, 3) void gemm_fp6_n64_kernel(GemmFp6Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int tiles_n = g.tiles_n * 2;                              // 64-column tiles
+  const int nwg = g.tiles_m * tiles_n;
+  const int KB = g.K / 128;
+  const int gstride = (int)gridDim.x;
+  auto tile_of = [&](int p, int& bm, int& bn) {
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = p & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (p >> 3);
+    constexpr int GROUP_M = T128_GROUP_M;
+    const int band = wgid / (GROUP_M * tiles_n);
+    const int band_rows = min(GROUP_M, g.tiles_m - band * GROUP_M);
+    const int in_band = wgid - band * GROUP_M * tiles_n;
+    bm = (band * GROUP_M + in_band % band_rows) * 128;
+    bn = (in_band / band_rows) * 64;
+  };
+  int p = blockIdx.x;
+  if (p >= nwg) return;
+  int bm, bn;
+  tile_of(p, bm, bn);
+  const int64_t plane_stride = (int64_t)(g.tiles_n * 4) * KB * F6_PAIR;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned voff = (unsigned)lane * 16u;
+  auto glds = [&](const unsigned char* sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+  };
+  // 42 pieces of 1 KB per stage: A 12 (4 pairs x 3), each plane 6 (2 pairs x 3); piece idx = w + 4 i
+  auto issue = [&](int kb, int tbm, int tbn) {
+    const unsigned char* a_src = g.A6 + ((int64_t)(tbm / 32) * KB + kb) * F6_PAIR;
+    const unsigned char* w_src = g.W6 + ((int64_t)(tbn / 32) * KB + kb) * F6_PAIR;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+      const int idx = w + 4 * i;
+      if (idx >= 42) break;
+      const unsigned char* src; unsigned dst;
+      if (idx < 12) { const int pair = idx / 3, sub = idx - pair * 3; src = a_src + (int64_t)pair * KB * F6_PAIR + sub * 1024; dst = (unsigned)(idx * 1024); }
+      else {
+        const int j = idx - 12, plane = j / 6, piece = j - plane * 6, pair = piece / 3, sub = piece - pair * 3;
+        src = w_src + (int64_t)plane * plane_stride + (int64_t)pair * KB * F6_PAIR + sub * 1024;
+        dst = (unsigned)(F6_PLANE + plane * N64_PLANE + piece * 1024);
+      }
+      glds(src, lds0 + dst);
+    }
+  };
+  auto frag = [&](int plane_off, int r) -> v8i {
+    const char* pb = smem + plane_off + (r >> 1) * F6_PAIR;
+    const uint4 a = *reinterpret_cast<const uint4*>(pb + (r & 1) * 1024 + lane * 16);
+    const uint2 b = *reinterpret_cast<const uint2*>(pb + 2048 + (r & 1) * 512 + lane * 8);
+    v8i v; v[0] = (int)a.x; v[1] = (int)a.y; v[2] = (int)a.z; v[3] = (int)a.w; v[4] = (int)b.x; v[5] = (int)b.y; v[6] = 0; v[7] = 0;
+    return v;
+  };
+  f32x4 acc[4][2];
+  int prio_ctr = (int)(blockIdx.x / (gridDim.x / 3 > 0 ? gridDim.x / 3 : 1));
+  int stage_ctr = 0;
+  issue(0, bm, bn);
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    const int pn = p + gstride;
+    const bool more = pn < nwg;
+    int nbm = 0, nbn = 0;
+    if (more) tile_of(pn, nbm, nbn);
+    for (int kb = 0; kb < KB; ++kb) {
+      {                                                      // the CU's three workgroups take the issue priorities in turn (as the production kernel)
+        const int per = max(1, (KB * ((nwg + gstride - 1) / gstride) + 5) / 6);
+        if (stage_ctr % per == 0) { const int pr = (prio_ctr + stage_ctr / per) % 3; if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
+        ++stage_ctr;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      v8i fa[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fa[t] = frag(0, 4 * wm + t);
+#pragma unroll
+      for (int pl = 0; pl < FP6_NL; ++pl) {
+        v8i fb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fb[t] = frag(F6_PLANE + pl * N64_PLANE, 2 * wn + t);
+        const int sb = 127 + 3 + 5 * pl;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[tm], fb[tn], acc[tm][tn], 2, 2, 0, 127, 0, sb);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+      if (kb + 1 < KB) issue(kb + 1, bm, bn);
+    }
+    float4 ep_rs, ep_bv;
+    {
+      const int n = bn + wn * 32 + (lane & 7) * 4;
+      ep_rs = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv = ep_rs;
+      if (n < g.N) { ep_rs = *reinterpret_cast<const float4*>(g.rowscale + n); if (g.bias) ep_bv = *reinterpret_cast<const float4*>(g.bias + n); }
+    }
+    {
+      char* eb = smem + w * EPI_WAVE;
+      const int c4 = (lane & 7) * 4;
+      const int n = bn + wn * 32 + c4;
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + l15 * 4) = acc[tm][0][e];
+          *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + (16 + l15) * 4) = acc[tm][1][e];
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int r16 = it * 8 + (lane >> 3);
+          const float4 v = *reinterpret_cast<const float4*>(eb + r16 * 144 + c4 * 4);
+          const int m = bm + wm * 64 + tm * 16 + r16;
+          float4 o;
+          o.x = v.x * ep_rs.x + ep_bv.x; o.y = v.y * ep_rs.y + ep_bv.y; o.z = v.z * ep_rs.z + ep_bv.z; o.w = v.w * ep_rs.w + ep_bv.w;
+          if (n < g.N && m < g.M) *reinterpret_cast<float4*>(g.y + (int64_t)m * g.N + n) = o;
+        }
+      }
+    }
+    if (!more) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+    issue(0, nbm, nbn);
+    p = pn; bm = nbm; bn = nbn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // The ring form: 256 x 128 tiles, 12 waves -- waves 0..7 compute (4 x 2 of 64 x 64 outputs), waves 8..11 only copy.  A 128-deep k
 // block is seven ITEMS of 12 KB (A rows 0..127, A rows 128..255, the five digit planes); the LDS holds a ring of RING_NS such slots.
 // Loader wave j copies pieces 3j..3j+2 of every item (scalar base + lane offset, LDS-DMA), confirms an item RING_LOOK items later
@@ -680,6 +820,16 @@ int main() {      // timing of the ring kernel alone on random operand bytes (ev
     int herr = 0; hipMemcpy(&herr, derr, 4, hipMemcpyDeviceToHost);
     printf("ring NS=%d LOOK=%d DIAG=%d: %.1f us (%d time-outs)\n", RING_NS, RING_LOOK, RING_DIAG, ms * 5.f, herr);
   }
+  {   // the 128 x 64 transplant, three workgroups per CU
+    hipFuncSetAttribute((const void*)gemm_fp6_n64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, N64_STAGE);
+    const unsigned g6 = std::min<unsigned>((M / 128) * (N / 64), 3 * gemm_grid(1 << 30));
+    for (int rep = 0; rep < 3; ++rep) {
+      float ms;
+      for (int i = 0; i < 20; ++i) gemm_fp6_n64_kernel<<<g6, 256, N64_STAGE>>>(fr.f);
+      hipEventRecord(a); for (int i = 0; i < 200; ++i) gemm_fp6_n64_kernel<<<g6, 256, N64_STAGE>>>(fr.f); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+      printf("128 x 64 transplant (three workgroups per CU): %.1f us\n", ms * 5.f);
+    }
+  }
   {   // the eight-wave transplant on the same operands
     hipFuncSetAttribute((const void*)gemm_fp6_w8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F6_STAGE);
     const unsigned g8 = std::min<unsigned>((M / 128) * (N / 128), 2 * gemm_grid(1 << 30));
@@ -785,6 +935,21 @@ int main(int argc, char** argv) {
     std::vector<float> hr((size_t)M * N); hipMemcpy(hr.data(), y6r, hr.size() * 4, hipMemcpyDeviceToHost);
     size_t diff = 0; for (size_t i = 0; i < hr.size(); ++i) diff += hr[i] != h6[i];
     printf("ring kernel: %d waves timed out; %zu of %zu outputs differ from the transplant kernel's (same products, same order per output)\n", herr, diff, hr.size()); }
+  {   // the 128 x 64 transplant: same products per output in the same order -> bit-identical to the 128 x 128 transplant
+    float* y64; hipMalloc(&y64, (size_t)M * N * 4); hipMemset(y64, 0, (size_t)M * N * 4);
+    GemmFp6Args f64 = f; f64.y = y64;
+    hipFuncSetAttribute((const void*)gemm_fp6_n64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, N64_STAGE);
+    const unsigned g64 = std::min<unsigned>((M / 128) * (N / 64), 3 * cus);
+    gemm_fp6_n64_kernel<<<g64, 256, N64_STAGE>>>(f64);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("n64 kernel failed\n"); return 1; }
+    std::vector<float> hn((size_t)M * N); hipMemcpy(hn.data(), y64, hn.size() * 4, hipMemcpyDeviceToHost);
+    size_t diff = 0; for (size_t i = 0; i < hn.size(); ++i) diff += hn[i] != h6[i];
+    printf("128 x 64 transplant: %zu of %zu outputs differ from the 128 x 128 transplant's\n", diff, hn.size());
+    hipEvent_t a2, b2; hipEventCreate(&a2); hipEventCreate(&b2); float ms;
+    for (int i = 0; i < 10; ++i) gemm_fp6_n64_kernel<<<g64, 256, N64_STAGE>>>(f64);
+    hipEventRecord(a2); for (int i = 0; i < 100; ++i) gemm_fp6_n64_kernel<<<g64, 256, N64_STAGE>>>(f64); hipEventRecord(b2); hipEventSynchronize(b2); hipEventElapsedTime(&ms, a2, b2);
+    printf("128 x 64 transplant (three workgroups per CU): %.1f us\n", ms * 10.f);
+  }
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int rep = 0; rep < 3; ++rep) {
     float ms16, ms6;
