@@ -55,6 +55,8 @@ struct GemmFp6Args {
   float* y;
   int M, N, K;                  // K % 128 == 0
   int tiles_m, tiles_n;         // 128 x 128 tiles
+  // LoRA-up stages (gemm_fp6_t128_kernel only; Rp = 0: none): the production kernel's fp16 limb operands, [Mp, Rp] / [Np, Rp], Rp % 64 == 0
+  const _Float16 *thi, *tlo, *Bhi, *Blo; const float* rowinv; int Rp;
 };
 
 __global__ __launch_bounds__(256, FP6_WGS) void gemm_fp6_t128_kernel(GemmFp6Args g) {
@@ -86,6 +88,12 @@ __global__ __launch_bounds__(256, FP6_WGS) void gemm_fp6_t128_kernel(GemmFp6Args
   // copies: a plane of a stage is 4 pairs x 3 KB = 12 pieces of 1 KB; wave w takes pieces 3w .. 3w+2 of every plane (scalar base +
   // per-lane offset, inline asm: the builtin form kept 36 address registers alive through the stage loop)
   auto glds = [&](const unsigned char* sbase, unsigned lds_addr) {
+    {   // (wave-uniform by construction; say so to the compiler: the "s" constraint needs scalar registers)
+      const unsigned long long a64 = (unsigned long long)sbase;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a64), hi = __builtin_amdgcn_readfirstlane((unsigned)(a64 >> 32));
+      sbase = (const unsigned char*)(((unsigned long long)hi << 32) | lo);
+      lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    }
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
   };
   auto issue = [&](int kb, int tbm, int tbn) {
@@ -111,6 +119,51 @@ __global__ __launch_bounds__(256, FP6_WGS) void gemm_fp6_t128_kernel(GemmFp6Args
   f32x4 acc[4][4];
   int prio_ctr = (int)(blockIdx.x / (gridDim.x / FP6_WGS > 0 ? gridDim.x / FP6_WGS : 1));
   int stage_ctr = 0;
+#ifndef RING_ONLY
+  // ---- LoRA-up stages: the production kernel's (fp16 limbs, 64-deep, [A 16 KB | B-hi 16 KB | B-lo 16 KB] with its XOR swizzle, v_mfma_f32_16x16x32_f16
+  // into the SAME accumulators: the C/D layout does not depend on the operand type)
+  const int nlb = g.Rp / 64;                                  // 64-deep blocks of the rank
+  const int prow8 = lane >> 3, pchunk = lane & 7;
+  auto issue_lora = [&](int j, int which, int tbm, int tbn) {
+    const _Float16* A = (which ? g.tlo : g.thi) + (int64_t)tbm * g.Rp + j * 64;
+    const _Float16* Bh = g.Bhi + (int64_t)tbn * g.Rp + j * 64;
+    const _Float16* Bl = g.Blo + (int64_t)tbn * g.Rp + j * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (4 * w + i) * 8 + prow8, col = swz(row, pchunk) * 8;
+      glds16(A + (row * g.Rp + col), smem + (4 * w + i) * 1024);
+      if (!which) { glds16(Bh + (row * g.Rp + col), smem + 16384 + (4 * w + i) * 1024); glds16(Bl + (row * g.Rp + col), smem + 32768 + (4 * w + i) * 1024); }
+    }
+  };
+  auto lora_stage = [&](bool two) {                          // one operand set live at a time (the stage is 2 of 8: registers matter more than overlap here)
+    const int sx7 = (l15 >> 1) & 7;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int koff = ((4 * s2 + q4) ^ sx7) * 16;
+      f16x8 a[4], bb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = *reinterpret_cast<const f16x8*>(smem + (wm * 64 + l15) * 128 + t * 2048 + koff);
+        bb[t] = *reinterpret_cast<const f16x8*>(smem + 16384 + (wn * 64 + l15) * 128 + t * 2048 + koff);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (two) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bb[t] = *reinterpret_cast<const f16x8*>(smem + 32768 + (wn * 64 + l15) * 128 + t * 2048 + koff);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  if (nlb > 0) issue_lora(0, 0, bm, bn); else
+#endif
   issue(0, bm, bn);
   while (true) {
 #pragma unroll
@@ -123,6 +176,28 @@ __global__ __launch_bounds__(256, FP6_WGS) void gemm_fp6_t128_kernel(GemmFp6Args
     const bool more = pn < nwg;
     int nbm = 0, nbn = 0;
     if (more) tile_of(pn, nbm, nbn);
+#ifndef RING_ONLY
+    for (int j = 0; j < nlb; ++j) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+      lora_stage(true);                                      // thi x {Bhi, Blo}
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+      issue_lora(j, 1, bm, bn);                              // tlo; its B-hi is still in the buffer
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+      lora_stage(false);                                     // tlo x Bhi
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+      if (j + 1 < nlb) issue_lora(j + 1, 0, bm, bn); else issue(0, bm, bn);
+    }
+    if (nlb > 0) {                                           // LoRA partial sums (units 2^e16[n] 2^g[m]) -> units of the digit sum: * 2^-g[m] * 2^(E6 - e16) = rowinv[m] * 2^10
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        const f32x4 riv = *reinterpret_cast<const f32x4*>(g.rowinv + bm + wm * 64 + tm * 16 + 4 * q4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) acc[tm][tn][e] *= riv[e] * 1024.f;
+      }
+    }
+#endif
     for (int kb = 0; kb < KB; ++kb) {
       {                                                      // the CU's workgroups take the issue priorities in turn (as the production kernel)
         const int per = max(1, (KB * ((nwg + gstride - 1) / gstride) + 5) / 6);
@@ -149,16 +224,10 @@ __global__ __launch_bounds__(256, FP6_WGS) void gemm_fp6_t128_kernel(GemmFp6Args
             acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[tm], fb[tn], acc[tm][tn], 2, 2, 0, 127, 0, sb);
         __builtin_amdgcn_sched_barrier(0);
       };
-      load_plane(b0, 0);
-      static_assert(FP6_NL == 5 || FP6_NL == 4 || FP6_NL == 6, "planes are unrolled by hand");
-      load_plane(b1, 1); mfma_plane(b0, 0);
-      load_plane(b0, 2); mfma_plane(b1, 1);
-      load_plane(b1, 3); mfma_plane(b0, 2);
-      if (FP6_NL >= 5) load_plane(b0, 4);
-      mfma_plane(b1, 3);
-      if (FP6_NL >= 6) load_plane(b1, 5);
-      if (FP6_NL >= 5) mfma_plane(b0, 4);
-      if (FP6_NL >= 6) mfma_plane(b1, 5);
+      // one fragment set, plane after plane (two sets overlapped reads and MFMAs but cost 256 VGPRs and scratch: the CU's other workgroup covers the reads)
+#pragma unroll
+      for (int pl = 0; pl < FP6_NL; ++pl) { load_plane(b0, pl); mfma_plane(b0, pl); asm volatile("" ::: "memory"); }
+      (void)b1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave has read its fragments
       if (kb + 1 < KB) issue(kb + 1, bm, bn);
@@ -203,6 +272,9 @@ __global__ __launch_bounds__(256, FP6_WGS) void gemm_fp6_t128_kernel(GemmFp6Args
     if (!more) break;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+#ifndef RING_ONLY
+    if (nlb > 0) issue_lora(0, 0, nbm, nbn); else
+#endif
     issue(0, nbm, nbn);
     p = pn; bm = nbm; bn = nbn;
   }
@@ -887,6 +959,20 @@ int main(int argc, char** argv) {
     }
   }
   printf("digits: %d planes, worst |W' - digits| / rowmax = %.3g (f16 limbs: 2^-22 = %.3g of the element)\n", FP6_NL, digit_err, ldexp(1.0, -22));
+  // ---- LoRA-up operands, as the production activation pass / preparation make them: t 2^g[m] = thi + tlo, B' 2^e16[n] = Bhi + Blo
+  const int R = 64;
+  std::vector<float> tt((size_t)M * R), Bp((size_t)N * R), rowinv(M);
+  std::vector<_Float16> thi((size_t)M * R), tlo((size_t)M * R), bhi((size_t)N * R), blo((size_t)N * R);
+  { std::normal_distribution<float> n1(0.f, 1.f);
+    for (auto& v : tt) v = n1(rng);
+    for (auto& v : Bp) v = n1(rng) * 0.01f; }
+  for (int m = 0; m < M; ++m) {
+    float mx = 0; for (int j = 0; j < R; ++j) mx = fmaxf(mx, fabsf(tt[(size_t)m * R + j]));
+    int ex; frexpf(mx, &ex); const float pg = ldexpf(1.f, 14 - ex); rowinv[m] = 1.f / pg;
+    for (int j = 0; j < R; ++j) { const float v = tt[(size_t)m * R + j] * pg; const _Float16 h = (_Float16)v; thi[(size_t)m * R + j] = h; tlo[(size_t)m * R + j] = (_Float16)(v - (float)h); }
+  }
+  for (int n = 0; n < N; ++n)
+    for (int j = 0; j < R; ++j) { const float v = Bp[(size_t)n * R + j] / rs16[n]; const _Float16 h = (_Float16)v; bhi[(size_t)n * R + j] = h; blo[(size_t)n * R + j] = (_Float16)(v - (float)h); }
   auto up = [&](const void* h, size_t bytes) { void* d; hipMalloc(&d, bytes); hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); return d; };
   float *bias, *y16, *y6;
   hipMalloc(&bias, N * 4); hipMemset(bias, 0, N * 4);
@@ -894,14 +980,18 @@ int main(int argc, char** argv) {
   hipMemset(y16, 0, (size_t)M * N * 4); hipMemset(y6, 0, (size_t)M * N * 4);
   GemmF16Args g{};
   g.qx = (const _Float16*)up(qx.data(), qx.size() * 2); g.Whi = (const _Float16*)up(whi.data(), whi.size() * 2); g.Wlo = (const _Float16*)up(wlo.data(), wlo.size() * 2);
-  g.thi = g.tlo = g.Bhi = g.Blo = nullptr; g.rowinv = nullptr;
-  g.rowscale = (const float*)up(rs16.data(), N * 4); g.bias = bias; g.y = y16; g.M = M; g.N = N; g.Kp = K; g.Rp = 0;
+  g.thi = (const _Float16*)up(thi.data(), thi.size() * 2); g.tlo = (const _Float16*)up(tlo.data(), tlo.size() * 2);
+  g.Bhi = (const _Float16*)up(bhi.data(), bhi.size() * 2); g.Blo = (const _Float16*)up(blo.data(), blo.size() * 2); g.rowinv = (const float*)up(rowinv.data(), M * 4);
+  g.rowscale = (const float*)up(rs16.data(), N * 4); g.bias = bias; g.y = y16; g.M = M; g.N = N; g.Kp = K; g.Rp = R;
   g.tiles_m = M / GM; g.tiles_n = N / GN; g.a_limbs = 1; g.split = 1;
   GemmFp6Args f{};
   { auto pa = pack6(qc, M, K); f.A6 = (const unsigned char*)up(pa.data(), pa.size()); }
   { std::vector<unsigned char> all; for (int i = 0; i < FP6_NL; ++i) { auto pw = pack6(dc[i], N, K); all.insert(all.end(), pw.begin(), pw.end()); }
     f.W6 = (const unsigned char*)up(all.data(), all.size()); }
   f.rowscale = (const float*)up(rs6.data(), N * 4); f.bias = bias; f.y = y6; f.M = M; f.N = N; f.K = K; f.tiles_m = M / 128; f.tiles_n = N / 128;
+  f.thi = g.thi; f.tlo = g.tlo; f.Bhi = g.Bhi; f.Blo = g.Blo; f.rowinv = g.rowinv; f.Rp = 0;
+  float* y6L; hipMalloc(&y6L, (size_t)M * N * 4); hipMemset(y6L, 0, (size_t)M * N * 4);
+  GemmFp6Args fL = f; fL.Rp = R; fL.y = y6L;       // the same kernel WITH the LoRA-up stages: the like-for-like partner of the production kernel
   auto k16 = gemm_f16x2_t128_kernel<1, 0>;
   hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS);
   hipFuncSetAttribute((const void*)gemm_fp6_t128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F6_STAGE);
@@ -909,20 +999,22 @@ int main(int argc, char** argv) {
   const unsigned grid16 = std::min<unsigned>(2 * g.tiles_m * g.tiles_n, T128_WGS * cus), grid6 = std::min<unsigned>(f.tiles_m * f.tiles_n, FP6_WGS * cus);
   k16<<<grid16, 256, T128_LDS>>>(g);
   gemm_fp6_t128_kernel<<<grid6, 256, F6_STAGE>>>(f);
+  gemm_fp6_t128_kernel<<<grid6, 256, F6_STAGE>>>(fL);
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
   // ---- accuracy: both against a double sum on sampled rows, and against each other everywhere
-  std::vector<float> h16((size_t)M * N), h6((size_t)M * N);
-  hipMemcpy(h16.data(), y16, h16.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(h6.data(), y6, h6.size() * 4, hipMemcpyDeviceToHost);
+  std::vector<float> h16((size_t)M * N), h6((size_t)M * N), h6L((size_t)M * N);
+  hipMemcpy(h16.data(), y16, h16.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(h6.data(), y6, h6.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(h6L.data(), y6L, h6L.size() * 4, hipMemcpyDeviceToHost);
   double rms = 0; for (size_t i = 0; i < h16.size(); i += 97) rms += (double)h16[i] * h16[i]; rms = sqrt(rms / (h16.size() / 97));
   double e16 = 0, e6 = 0, e66 = 0;
   for (int m = 0; m < M; m += 257)
     for (int n = 0; n < N; ++n) {
       double s = 0; for (int k = 0; k < K; ++k) s += (double)q[(size_t)m * K + k] * (double)Wp[(size_t)n * K + k];
+      for (int j = 0; j < R; ++j) s += (double)tt[(size_t)m * R + j] * (double)Bp[(size_t)n * R + j];
       const double bound = 1e-5 * fabs(s) + 1e-5 * rms;
-      e16 = fmax(e16, fabs(h16[(size_t)m * N + n] - s) / bound); e6 = fmax(e6, fabs(h6[(size_t)m * N + n] - s) / bound);
+      e16 = fmax(e16, fabs(h16[(size_t)m * N + n] - s) / bound); e6 = fmax(e6, fabs(h6L[(size_t)m * N + n] - s) / bound);
     }
-  for (size_t i = 0; i < h16.size(); ++i) e66 = fmax(e66, fabs((double)h16[i] - h6[i]) / (1e-5 * fabs((double)h16[i]) + 1e-5 * rms));
-  printf("max err / (1e-5 |y| + 1e-5 rms): f16 limbs vs double %.3f, FP6 digits vs double %.3f (sampled rows); FP6 vs f16 limbs, every output %.3f\n", e16, e6, e66);
+  for (size_t i = 0; i < h16.size(); ++i) e66 = fmax(e66, fabs((double)h16[i] - h6L[i]) / (1e-5 * fabs((double)h16[i]) + 1e-5 * rms));
+  printf("WITH the LoRA-up stages in both kernels -- max err / (1e-5 |y| + 1e-5 rms): f16 limbs vs double %.3f, FP6 digits vs double %.3f (sampled rows); FP6 vs f16 limbs, every output %.3f\n", e16, e6, e66);
   // ---- the ring form
   float* y6r; hipMalloc(&y6r, (size_t)M * N * 4); hipMemset(y6r, 0, (size_t)M * N * 4);
   int* derr; hipMalloc(&derr, 4); hipMemset(derr, 0, 4);
@@ -955,13 +1047,13 @@ int main(int argc, char** argv) {
     float ms16, ms6;
     for (int i = 0; i < 10; ++i) k16<<<grid16, 256, T128_LDS>>>(g);
     hipEventRecord(a); for (int i = 0; i < 100; ++i) k16<<<grid16, 256, T128_LDS>>>(g); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms16, a, b);
-    for (int i = 0; i < 10; ++i) gemm_fp6_t128_kernel<<<grid6, 256, F6_STAGE>>>(f);
-    hipEventRecord(a); for (int i = 0; i < 100; ++i) gemm_fp6_t128_kernel<<<grid6, 256, F6_STAGE>>>(f); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms6, a, b);
+    for (int i = 0; i < 10; ++i) gemm_fp6_t128_kernel<<<grid6, 256, F6_STAGE>>>(fL);
+    hipEventRecord(a); for (int i = 0; i < 100; ++i) gemm_fp6_t128_kernel<<<grid6, 256, F6_STAGE>>>(fL); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms6, a, b);
     float msr;
     for (int i = 0; i < 10; ++i) gemm_fp6_ring_kernel<<<gridr, 768, RING_LDS>>>(fr);
     hipEventRecord(a); for (int i = 0; i < 100; ++i) gemm_fp6_ring_kernel<<<gridr, 768, RING_LDS>>>(fr); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&msr, a, b);
     printf("FP6 ring kernel (256 x 128 tiles, 8 compute + 4 loader waves, %d slots, look-ahead %d): %.1f us\n", RING_NS, RING_LOOK, msr * 10.f);
-    printf("base contraction 8192 x 768 x 3072 (no LoRA stages): f16 limbs (2 MFMA 16x16x32 per 32 k) %.1f us | FP6 digits (%d MFMA 16x16x128 per 128 k, %d workgroups per CU) %.1f us\n",
+    printf("whole contraction 8192 x 768 x 3072 + LoRA-up r = 64 (the headline): production kernel, f16 limbs (2 MFMA 16x16x32 per 32 k) %.1f us | FP6 digits (%d MFMA 16x16x128 per 128 k, %d workgroups per CU) + the same f16 LoRA stages %.1f us\n",
            ms16 * 10.f, FP6_NL, FP6_WGS, ms6 * 10.f);
   }
   return hipGetLastError() == hipSuccess ? 0 : 1;
