@@ -18,7 +18,6 @@ import torch
 
 from . import _lib
 from .blocks import SPLMHeadModel
-from .fake_quantize import _chan_view
 
 
 def _int_keys(d):
