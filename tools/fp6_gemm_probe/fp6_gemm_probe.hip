@@ -547,6 +547,148 @@ __global__ __launch_bounds__(256, 3) void gemm_fp6_n64_kernel(GemmFp6Args g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The transplant with its 72-KB stage cut into TWO HALF STAGES that double-buffer each other: X = {A, planes 0, 1} (36 KB),
+// Y = {planes 2, 3, 4} (36 KB).  While a workgroup multiplies X of k block kb, the copies of Y(kb) are in flight; while it multiplies
+// Y(kb), those of X(kb + 1) -- counted vmcnt, the A fragments stay in registers across both halves.  Same 128 x 128 tile, 4 waves,
+// two workgroups per CU, same bytes (663 MB) as the transplant.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int HS_HALF = 3 * F6_PLANE;                             // 36 KB
+__global__ __launch_bounds__(256, 2) void gemm_fp6_hs_kernel(GemmFp6Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int KB = g.K / 128;
+  const int gstride = (int)gridDim.x;
+  auto tile_of = [&](int p, int& bm, int& bn) {
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = p & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (p >> 3);
+    constexpr int GROUP_M = T128_GROUP_M;
+    const int band = wgid / (GROUP_M * g.tiles_n);
+    const int band_rows = min(GROUP_M, g.tiles_m - band * GROUP_M);
+    const int in_band = wgid - band * GROUP_M * g.tiles_n;
+    bm = (band * GROUP_M + in_band % band_rows) * 128;
+    bn = (in_band / band_rows) * 128;
+  };
+  int p = blockIdx.x;
+  if (p >= nwg) return;
+  int bm, bn;
+  tile_of(p, bm, bn);
+  const int64_t plane_stride = (int64_t)(g.tiles_n * 4) * KB * F6_PAIR;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned voff = (unsigned)lane * 16u;
+  auto glds = [&](const unsigned char* sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+  };
+  // a half stage = three 12-KB planes = 36 pieces of 1 KB; wave w takes pieces 3w..3w+2 of each plane (9 copies per wave and half)
+  auto issue_half = [&](int half, int kb, int tbm, int tbn) {       // half 0: A + planes 0, 1; half 1: planes 2, 3, 4
+    const unsigned char* a_src = g.A6 + ((int64_t)(tbm / 32 + w) * KB + kb) * F6_PAIR;      // pair w of the tile's rows
+    const unsigned char* w_src = g.W6 + ((int64_t)(tbn / 32 + w) * KB + kb) * F6_PAIR;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {                                     // plane j of the half
+      const unsigned char* src = (half == 0 && j == 0) ? a_src : w_src + (int64_t)(half == 0 ? j - 1 : 2 + j) * plane_stride;
+      const unsigned dst = lds0 + (unsigned)(half * HS_HALF + j * F6_PLANE + 3 * w * 1024);
+      glds(src, dst); glds(src + 1024, dst + 1024u); glds(src + 2048, dst + 2048u);
+    }
+  };
+  auto frag = [&](int off, int r) -> v8i {
+    const char* pb = smem + off + (r >> 1) * F6_PAIR;
+    const uint4 a = *reinterpret_cast<const uint4*>(pb + (r & 1) * 1024 + lane * 16);
+    const uint2 b = *reinterpret_cast<const uint2*>(pb + 2048 + (r & 1) * 512 + lane * 8);
+    v8i v; v[0] = (int)a.x; v[1] = (int)a.y; v[2] = (int)a.z; v[3] = (int)a.w; v[4] = (int)b.x; v[5] = (int)b.y; v[6] = 0; v[7] = 0;
+    return v;
+  };
+  f32x4 acc[4][4];
+  v8i fa[4], fb[4];
+  auto plane = [&](int off, int pl) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fb[t] = frag(off, 4 * wn + t);
+    const int sb = 127 + 3 + 5 * pl;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[tm], fb[tn], acc[tm][tn], 2, 2, 0, 127, 0, sb);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+  };
+  issue_half(0, 0, bm, bn);
+  issue_half(1, 0, bm, bn);
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    const int pn = p + gstride;
+    const bool more = pn < nwg;
+    int nbm = 0, nbn = 0;
+    if (more) tile_of(pn, nbm, nbn);
+#pragma unroll 1
+    for (int kb = 0; kb < KB; ++kb) {
+      const bool last = kb + 1 == KB;
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");         // X(kb) has landed; the nine copies of Y(kb) may still fly
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fa[t] = frag(0, 4 * wm + t);
+      plane(F6_PLANE, 0); plane(2 * F6_PLANE, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave is done with X
+      if (!last) issue_half(0, kb + 1, bm, bn);
+      if (!last) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Y(kb) has landed
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+      plane(HS_HALF, 2); plane(HS_HALF + F6_PLANE, 3); plane(HS_HALF + 2 * F6_PLANE, 4);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave is done with Y
+      if (!last) issue_half(1, kb + 1, bm, bn);
+      else if (more) issue_half(1, 0, nbm, nbn);                // the next tile's Y half under the epilogue (its X half after it: the slices live there)
+    }
+    float4 ep_rs[2], ep_bv[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
+      ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
+      if (n < g.N) { ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n); if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n); }
+    }
+    {
+      char* eb = smem + w * EPI_WAVE;
+      const int c4 = (lane & 7) * 4;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int n = bn + wn * 64 + tn * 32 + c4;
+        const float4 rs = ep_rs[tn], bv = ep_bv[tn];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + l15 * 4) = acc[tm][2 * tn][e];
+            *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + (16 + l15) * 4) = acc[tm][2 * tn + 1][e];
+          }
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int r16 = it * 8 + (lane >> 3);
+            const float4 v = *reinterpret_cast<const float4*>(eb + r16 * 144 + c4 * 4);
+            const int m = bm + wm * 64 + tm * 16 + r16;
+            float4 o;
+            o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
+            if (n < g.N && m < g.M) *reinterpret_cast<float4*>(g.y + (int64_t)m * g.N + n) = o;
+          }
+        }
+      }
+    }
+    if (!more) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");     // the slices are done with
+    // the epilogue's stores are ordinary VMEM operations: they sit in the same in-order vmcnt as the Y copies issued before them
+    issue_half(0, 0, nbm, nbn);
+    p = pn; bm = nbm; bn = nbn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // The ring form: 256 x 128 tiles, 12 waves -- waves 0..7 compute (4 x 2 of 64 x 64 outputs), waves 8..11 only copy.  A 128-deep k
 // block is seven ITEMS of 12 KB (A rows 0..127, A rows 128..255, the five digit planes); the LDS holds a ring of RING_NS such slots.
 // Loader wave j copies pieces 3j..3j+2 of every item (scalar base + lane offset, LDS-DMA), confirms an item RING_LOOK items later
@@ -892,6 +1034,16 @@ int main() {      // timing of the ring kernel alone on random operand bytes (ev
     int herr = 0; hipMemcpy(&herr, derr, 4, hipMemcpyDeviceToHost);
     printf("ring NS=%d LOOK=%d DIAG=%d: %.1f us (%d time-outs)\n", RING_NS, RING_LOOK, RING_DIAG, ms * 5.f, herr);
   }
+  {   // the half-stage double-buffered transplant
+    hipFuncSetAttribute((const void*)gemm_fp6_hs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F6_STAGE);
+    const unsigned gh = std::min<unsigned>((M / 128) * (N / 128), 2 * gemm_grid(1 << 30));
+    for (int rep = 0; rep < 3; ++rep) {
+      float ms;
+      for (int i = 0; i < 20; ++i) gemm_fp6_hs_kernel<<<gh, 256, F6_STAGE>>>(fr.f);
+      hipEventRecord(a); for (int i = 0; i < 200; ++i) gemm_fp6_hs_kernel<<<gh, 256, F6_STAGE>>>(fr.f); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+      printf("half-stage double-buffered transplant (128 x 128 tiles, two workgroups per CU): %.1f us\n", ms * 5.f);
+    }
+  }
   {   // the 128 x 64 transplant, three workgroups per CU
     hipFuncSetAttribute((const void*)gemm_fp6_n64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, N64_STAGE);
     const unsigned g6 = std::min<unsigned>((M / 128) * (N / 64), 3 * gemm_grid(1 << 30));
@@ -1027,6 +1179,20 @@ int main(int argc, char** argv) {
     std::vector<float> hr((size_t)M * N); hipMemcpy(hr.data(), y6r, hr.size() * 4, hipMemcpyDeviceToHost);
     size_t diff = 0; for (size_t i = 0; i < hr.size(); ++i) diff += hr[i] != h6[i];
     printf("ring kernel: %d waves timed out; %zu of %zu outputs differ from the transplant kernel's (same products, same order per output)\n", herr, diff, hr.size()); }
+  {   // the half-stage double-buffered transplant: same products per output in the same order -> bit-identical
+    float* yh; hipMalloc(&yh, (size_t)M * N * 4); hipMemset(yh, 0, (size_t)M * N * 4);
+    GemmFp6Args fh = f; fh.y = yh;
+    hipFuncSetAttribute((const void*)gemm_fp6_hs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F6_STAGE);
+    gemm_fp6_hs_kernel<<<grid6, 256, F6_STAGE>>>(fh);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("hs kernel failed\n"); return 1; }
+    std::vector<float> hh((size_t)M * N); hipMemcpy(hh.data(), yh, hh.size() * 4, hipMemcpyDeviceToHost);
+    size_t diff = 0; for (size_t i = 0; i < hh.size(); ++i) diff += hh[i] != h6[i];
+    printf("half-stage double-buffered transplant: %zu of %zu outputs differ from the transplant's\n", diff, hh.size());
+    hipEvent_t a2, b2; hipEventCreate(&a2); hipEventCreate(&b2); float ms;
+    for (int i = 0; i < 10; ++i) gemm_fp6_hs_kernel<<<grid6, 256, F6_STAGE>>>(fh);
+    hipEventRecord(a2); for (int i = 0; i < 100; ++i) gemm_fp6_hs_kernel<<<grid6, 256, F6_STAGE>>>(fh); hipEventRecord(b2); hipEventSynchronize(b2); hipEventElapsedTime(&ms, a2, b2);
+    printf("half-stage double-buffered transplant: %.1f us\n", ms * 10.f);
+  }
   {   // the 128 x 64 transplant: same products per output in the same order -> bit-identical to the 128 x 128 transplant
     float* y64; hipMalloc(&y64, (size_t)M * N * 4); hipMemset(y64, 0, (size_t)M * N * 4);
     GemmFp6Args f64 = f; f64.y = y64;
