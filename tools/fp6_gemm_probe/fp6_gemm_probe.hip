@@ -706,6 +706,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fp6_hs_kernel(GemmFp6Args g) {
 #ifndef RING_HYST
 #define RING_HYST 3
 #endif
+#ifndef RING_B64
+#define RING_B64 0
+#endif
 #ifndef RING_AREG      // 1: the activation fragments go global -> registers in the compute waves; the ring carries the digit planes only
 #define RING_AREG 0
 #endif
@@ -837,10 +840,18 @@ __global__ __launch_bounds__(768, 1) void gemm_fp6_ring_kernel(GemmFp6RingArgs g
   const int my_half = wm >> 1;                                     // which A item this wave reads
   auto frag = [&](unsigned item_base, int r) -> v8i {
     const char* pb = smem + item_base + (r >> 1) * F6_PAIR;
+#if RING_B64      // three 8-B reads instead of 16 B + 8 B: does hipcc place them into the operand tuple without copies?
+    const uint2 a0 = *reinterpret_cast<const uint2*>(pb + (r & 1) * 1024 + lane * 16);
+    const uint2 a1 = *reinterpret_cast<const uint2*>(pb + (r & 1) * 1024 + lane * 16 + 8);
+    const uint2 b = *reinterpret_cast<const uint2*>(pb + 2048 + (r & 1) * 512 + lane * 8);
+    v8i v; v[0] = (int)a0.x; v[1] = (int)a0.y; v[2] = (int)a1.x; v[3] = (int)a1.y; v[4] = (int)b.x; v[5] = (int)b.y; v[6] = 0; v[7] = 0;
+    return v;
+#else
     const uint4 a = *reinterpret_cast<const uint4*>(pb + (r & 1) * 1024 + lane * 16);
     const uint2 b = *reinterpret_cast<const uint2*>(pb + 2048 + (r & 1) * 512 + lane * 8);
     v8i v; v[0] = (int)a.x; v[1] = (int)a.y; v[2] = (int)a.z; v[3] = (int)a.w; v[4] = (int)b.x; v[5] = (int)b.y; v[6] = 0; v[7] = 0;
     return v;
+#endif
   };
   f32x4 acc[4][4];
   int gi = 0, ready = 0, dummy = 0;
