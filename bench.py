@@ -295,8 +295,6 @@ def main():
     with torch.no_grad():
         for _ in range(max(0, args.setup_steps)):          # setup, not warm-up: workspace growth, code-object load, clock ramp
             y = layer(x)
-        for _ in range(args.warmup):
-            y = layer(x)
         # the dominant kernel is timed live inside the timed region, on every EVERY-th step (an event pair costs two marker
         # packets on the launch stream; on every step that alone took 8 % off the throughput it was meant to explain); EVERY
         # is chosen so that even a 20-step run averages over >= 8 launches
@@ -308,19 +306,29 @@ def main():
         n_main = (args.steps + EVERY - 1) // EVERY
         n_extra = max(0, 8 - n_main)      # a short run: further samples ride on the first repeat region below, >= 8 launches in all
         ev = HipEvents(n_main + n_extra)
+        import gc
+        gc.collect(); gc.disable()        # a collector pause of the host inside a 2-ms region is a 10-20 % outlier (seen: 0.119 against 0.097 ms/step)
+        # All host-side preparation (events, the collector) happens BEFORE the W warm-up steps, so that the timed region follows GPU work,
+        # not an idle gap: the chip drops its clock within milliseconds of idling and the first ~1 ms after that runs slow -- with the
+        # event creation between warm-up and region the FIRST region read 0.110-0.119 ms/step where the repeats right after it read 0.100.
+        for _ in range(args.warmup):
+            y = layer(x)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            layer._gemm_events = ev.pairs[i // EVERY] if i % EVERY == 0 else None
+            # (a sample sits on the LAST step of its group of EVERY: in a 20-step region the one pair then lands at the region's end, where its two
+            # marker packets delay nothing behind them -- at step 0 they sat in the launch ramp of the whole region)
+            layer._gemm_events = ev.pairs[i // EVERY] if (i % EVERY == EVERY - 1 or i == args.steps - 1) and i // EVERY < n_main else None
             y = layer(x)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         layer._gemm_events = None
         # median / min over repeats of the same K-step region (no event markers), SURVEY.md §8d
         repeats = []
@@ -405,6 +413,28 @@ def main():
                    "f16x2-limb operands, f32 accumulate (fp32-accurate)" if is_f16 else "f32")
         peak_s = ("i8 dense MFMA (2x the f16 rate; one product per algorithmic product)" if is_i8 else
                   "f16 dense MFMA (2 limb products per algorithmic product)" if is_f16 else "f32-input MFMA")
+        # a yardstick, not part of the product: the SAME limb products as one plain fp16 GEMM of the vendor library (torch.mm -> hipBLASLt) --
+        # [q | q] . [Whi | Wlo]^T and [thi | thi | tlo] . [Bhi | Blo | Bhi]^T concatenated along K -- timed live on this box (rank 0, one GPU)
+        yard = None
+        if world == 1 and is_f16 and not is_i8:
+            try:
+                kq = 2 * K_IN + 3 * ((RANK + 63) // 64 * 64)
+                ya = torch.randint(-7, 8, (M_TOKENS, kq), device=dev).half()
+                yb = (torch.randn(N_OUT, kq, device=dev) * 100).half()
+                for _ in range(10):
+                    torch.mm(ya, yb.t(), out_dtype=torch.float32)
+                torch.cuda.synchronize()
+                y0, y1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                y0.record()
+                for _ in range(50):
+                    torch.mm(ya, yb.t(), out_dtype=torch.float32)
+                y1.record(); y1.synchronize()
+                yard = {"ms": round(y0.elapsed_time(y1) / 50, 4),
+                        "what": f"torch.mm (hipBLASLt) fp16 [{M_TOKENS} x {kq}] . [{kq} x {N_OUT}] -> fp32: the contraction kernel's limb products (2 per "
+                                "weight, 3 per LoRA-B element) as ONE plain GEMM, without its rescale / row scale / bias; a reference, not the product"}
+                del ya, yb
+            except Exception as ex:                       # (an older torch without out_dtype: skip the yardstick)
+                yard = {"ms": None, "what": f"not measured: {type(ex).__name__}"}
         out = {
             "metric": "fused quant-GEMM-LoRA fwd GFLOP/s per GPU, GPT-2 c_fc 768→3072 @ 4-bit",
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -441,6 +471,7 @@ def main():
                          "kernel_launches_timed": len(gemm_ms), "peak_dtype": peak_s, "kernel_ms_avg": round(gemm_avg_ms, 4),
                          "frac_vs_f16_mfma_peak": round(achieved / PEAK["f16"], 4),
                          "kernel_ms_min": round(min(gemm_ms), 4) if gemm_ms else None,
+                         "vendor_gemm_same_limb_products": yard,
                          "frac_vs_f32_mfma_peak": round(achieved / PEAK["f32"], 4),
                          # the contraction on its OWN flops (2MKN + 2MrN: the LoRA-down product 2MKr runs in the activation pass)
                          "achieved_own_flops": round((FLOP_PER_STEP - 2 * M_TOKENS * K_IN * RANK) / (gemm_avg_ms * 1e-3) / 1e12, 2) if gemm_avg_ms > 0 else None,
