@@ -689,6 +689,159 @@ __global__ __launch_bounds__(256, 2) void gemm_fp6_hs_kernel(GemmFp6Args g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The double-buffered form: 256 x 128 tiles, ONE workgroup of 8 waves per CU (4 x 2 of 64 x 64 outputs), the activation fragments straight
+// from global memory into registers (one k block ahead), the five digit planes of a k block (60 KB) in one of TWO LDS buffers: every
+// wave issues its share of the next k block's plane copies (60 pieces of 1 KB: 7 or 8 per wave) at the top of a k block and then
+// multiplies the current one -- one vmcnt(0) + one barrier per k block, no counters.  The next tile's first k block is in flight
+// under the epilogue.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int DB_BUF = 5 * F6_PLANE;                              // 60 KB
+constexpr int DB_EPI_OFF = 2 * DB_BUF;
+constexpr int DB_LDS = DB_EPI_OFF + 8 * EPI_WAVE;                 // 138 KB
+__global__ __launch_bounds__(512, 2) void gemm_fp6_db_kernel(GemmFp6Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int tiles_m = g.tiles_m / 2;
+  const int nwg = tiles_m * g.tiles_n;
+  const int KB = g.K / 128;
+  const int gstride = (int)gridDim.x;
+  auto tile_of = [&](int p, int& bm, int& bn) {
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = p & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (p >> 3);
+    constexpr int GROUP_M = 4;
+    const int band = wgid / (GROUP_M * g.tiles_n);
+    const int band_rows = min(GROUP_M, tiles_m - band * GROUP_M);
+    const int in_band = wgid - band * GROUP_M * g.tiles_n;
+    bm = (band * GROUP_M + in_band % band_rows) * 256;
+    bn = (in_band / band_rows) * 128;
+  };
+  const int my_tiles = (nwg - (int)blockIdx.x + gstride - 1) / gstride;
+  const int64_t plane_stride = (int64_t)(g.tiles_n * 4) * KB * F6_PAIR;
+  const unsigned voff = (unsigned)lane * 16u;
+  auto glds = [&](const unsigned char* sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+  };
+  // Running source pointers: this wave's (up to) eight plane pieces and its four activation records of the CURRENT tile, + 3 KB per k block
+  // (per-copy 64-bit address arithmetic made hipcc spill scalar registers by the dozen).
+  const unsigned char* psrc[8]; unsigned pdst[8];
+  const unsigned char* asrc16[4]; const unsigned char* asrc8[4];
+  auto set_tile = [&](int tbm, int tbn) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = min(w + 8 * i, 59), plane = idx / 12, piece = idx - plane * 12, pair = piece / 3, sub = piece - pair * 3;
+      psrc[i] = g.W6 + (int64_t)plane * plane_stride + ((int64_t)(tbn / 32 + pair) * KB) * F6_PAIR + sub * 1024;
+      pdst[i] = (unsigned)(plane * F6_PLANE + piece * 1024);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rec = 4 * wm + t;
+      const unsigned char* pb = g.A6 + ((int64_t)(tbm / 32 + (rec >> 1)) * KB) * F6_PAIR;
+      asrc16[t] = pb + (rec & 1) * 1024 + lane * 16; asrc8[t] = pb + 2048 + (rec & 1) * 512 + lane * 8;
+    }
+  };
+  auto issue_next = [&](int buf, v8i (&fa)[4]) {                 // the next k block of the current pointers: plane copies + activation fragments; then advance
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (w + 8 * i < 60) glds(psrc[i], lds0 + (unsigned)(buf * DB_BUF) + pdst[i]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint4 a = *reinterpret_cast<const uint4*>(asrc16[t]);
+      const uint2 b2 = *reinterpret_cast<const uint2*>(asrc8[t]);
+      fa[t][0] = (int)a.x; fa[t][1] = (int)a.y; fa[t][2] = (int)a.z; fa[t][3] = (int)a.w; fa[t][4] = (int)b2.x; fa[t][5] = (int)b2.y; fa[t][6] = 0; fa[t][7] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) psrc[i] += F6_PAIR;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { asrc16[t] += F6_PAIR; asrc8[t] += F6_PAIR; }
+  };
+  auto frag = [&](unsigned off, int r) -> v8i {
+    const char* pb = smem + off + (r >> 1) * F6_PAIR;
+    const uint4 a = *reinterpret_cast<const uint4*>(pb + (r & 1) * 1024 + lane * 16);
+    const uint2 b2 = *reinterpret_cast<const uint2*>(pb + 2048 + (r & 1) * 512 + lane * 8);
+    v8i v; v[0] = (int)a.x; v[1] = (int)a.y; v[2] = (int)a.z; v[3] = (int)a.w; v[4] = (int)b2.x; v[5] = (int)b2.y; v[6] = 0; v[7] = 0;
+    return v;
+  };
+  f32x4 acc[4][4];
+  v8i fa[4], fan[4], fb[4];
+  int p = blockIdx.x, bm, bn;
+  tile_of(p, bm, bn);
+  set_tile(bm, bn);
+  int buf = 0;
+  issue_next(0, fan);
+  for (int ti = 0; ti < my_tiles; ++ti) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    const int pn = p + gstride;
+    const bool more = ti + 1 < my_tiles;
+    int nbm = bm, nbn = bn;
+    if (more) tile_of(pn, nbm, nbn);
+#pragma unroll 1
+    for (int kb = 0; kb < KB; ++kb) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my plane copies of this k block and my A fragments are here
+      __syncthreads();                                          // ... and everyone's; everyone is done with the other buffer
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fa[t] = fan[t];               // (24 register copies per k block instead of two code copies of the whole block)
+      const bool last = kb + 1 == KB;
+      if (last && more) set_tile(nbm, nbn);
+      if (!last || more) issue_next(buf ^ 1, fan);
+#pragma unroll
+      for (int pl = 0; pl < 5; ++pl) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fb[t] = frag((unsigned)(buf * DB_BUF + pl * F6_PLANE), 4 * wn + t);
+        const int sb = 127 + 3 + 5 * pl;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[tm], fb[tn], acc[tm][tn], 2, 2, 0, 127, 0, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+      }
+      buf ^= 1;
+    }
+    float4 ep_rs[2], ep_bv[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
+      ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
+      if (n < g.N) { ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n); if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n); }
+    }
+    char* eb = smem + DB_EPI_OFF + w * EPI_WAVE;
+    const int c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = bn + wn * 64 + tn * 32 + c4;
+      const float4 rs = ep_rs[tn], bv = ep_bv[tn];
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + l15 * 4) = acc[tm][2 * tn][e];
+          *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + (16 + l15) * 4) = acc[tm][2 * tn + 1][e];
+        }
+#pragma unroll
+        for (int it2 = 0; it2 < 2; ++it2) {
+          const int r16 = it2 * 8 + (lane >> 3);
+          const float4 v = *reinterpret_cast<const float4*>(eb + r16 * 144 + c4 * 4);
+          const int m = bm + wm * 64 + tm * 16 + r16;
+          float4 o;
+          o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
+          if (n < g.N && m < g.M) *reinterpret_cast<float4*>(g.y + (int64_t)m * g.N + n) = o;
+        }
+      }
+    }
+    p = pn; bm = nbm; bn = nbn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // The ring form: 256 x 128 tiles, 12 waves -- waves 0..7 compute (4 x 2 of 64 x 64 outputs), waves 8..11 only copy.  A 128-deep k
 // block is seven ITEMS of 12 KB (A rows 0..127, A rows 128..255, the five digit planes); the LDS holds a ring of RING_NS such slots.
 // Loader wave j copies pieces 3j..3j+2 of every item (scalar base + lane offset, LDS-DMA), confirms an item RING_LOOK items later
@@ -1045,6 +1198,16 @@ int main() {      // timing of the ring kernel alone on random operand bytes (ev
     int herr = 0; hipMemcpy(&herr, derr, 4, hipMemcpyDeviceToHost);
     printf("ring NS=%d LOOK=%d DIAG=%d: %.1f us (%d time-outs)\n", RING_NS, RING_LOOK, RING_DIAG, ms * 5.f, herr);
   }
+  {   // the double-buffered 256 x 128 form
+    hipFuncSetAttribute((const void*)gemm_fp6_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS);
+    const unsigned gd = std::min<unsigned>((M / 256) * (N / 128), gemm_grid(1 << 30));
+    for (int rep = 0; rep < 3; ++rep) {
+      float ms;
+      for (int i = 0; i < 20; ++i) gemm_fp6_db_kernel<<<gd, 512, DB_LDS>>>(fr.f);
+      hipEventRecord(a); for (int i = 0; i < 200; ++i) gemm_fp6_db_kernel<<<gd, 512, DB_LDS>>>(fr.f); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+      printf("double-buffered 256 x 128 form (8 waves, A fragments from global memory): %.1f us\n", ms * 5.f);
+    }
+  }
   {   // the half-stage double-buffered transplant
     hipFuncSetAttribute((const void*)gemm_fp6_hs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F6_STAGE);
     const unsigned gh = std::min<unsigned>((M / 128) * (N / 128), 2 * gemm_grid(1 << 30));
@@ -1190,6 +1353,21 @@ int main(int argc, char** argv) {
     std::vector<float> hr((size_t)M * N); hipMemcpy(hr.data(), y6r, hr.size() * 4, hipMemcpyDeviceToHost);
     size_t diff = 0; for (size_t i = 0; i < hr.size(); ++i) diff += hr[i] != h6[i];
     printf("ring kernel: %d waves timed out; %zu of %zu outputs differ from the transplant kernel's (same products, same order per output)\n", herr, diff, hr.size()); }
+  {   // the double-buffered 256 x 128 form: same products per output in the same order -> bit-identical
+    float* yd; hipMalloc(&yd, (size_t)M * N * 4); hipMemset(yd, 0, (size_t)M * N * 4);
+    GemmFp6Args fd = f; fd.y = yd;
+    hipFuncSetAttribute((const void*)gemm_fp6_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS);
+    const unsigned gd = std::min<unsigned>((M / 256) * (N / 128), cus);
+    gemm_fp6_db_kernel<<<gd, 512, DB_LDS>>>(fd);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("db kernel failed\n"); return 1; }
+    std::vector<float> hd((size_t)M * N); hipMemcpy(hd.data(), yd, hd.size() * 4, hipMemcpyDeviceToHost);
+    size_t diff = 0; for (size_t i = 0; i < hd.size(); ++i) diff += hd[i] != h6[i];
+    printf("double-buffered 256 x 128 form: %zu of %zu outputs differ from the transplant's\n", diff, hd.size());
+    hipEvent_t a2, b2; hipEventCreate(&a2); hipEventCreate(&b2); float ms;
+    for (int i = 0; i < 10; ++i) gemm_fp6_db_kernel<<<gd, 512, DB_LDS>>>(fd);
+    hipEventRecord(a2); for (int i = 0; i < 100; ++i) gemm_fp6_db_kernel<<<gd, 512, DB_LDS>>>(fd); hipEventRecord(b2); hipEventSynchronize(b2); hipEventElapsedTime(&ms, a2, b2);
+    printf("double-buffered 256 x 128 form: %.1f us\n", ms * 10.f);
+  }
   {   // the half-stage double-buffered transplant: same products per output in the same order -> bit-identical
     float* yh; hipMalloc(&yh, (size_t)M * N * 4); hipMemset(yh, 0, (size_t)M * N * 4);
     GemmFp6Args fh = f; fh.y = yh;
