@@ -689,6 +689,162 @@ __global__ __launch_bounds__(256, 2) void gemm_fp6_hs_kernel(GemmFp6Args g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The production kernel's recipe on FP6 operands: 128 x 128 tiles, 4 waves, ONE 36-KB buffer through which the half stages X = {A, planes
+// 0, 1} and Y = {planes 2, 3, 4} of every k block pass in turn (wait + barrier, multiply, barrier, issue the next half), the A fragments kept
+// in registers from X to Y -- so that THREE workgroups share a CU and fall out of step, as the f16-limb kernel's three do.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void gemm_fp6_h3_kernel(GemmFp6Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int KB = g.K / 128;
+  const int gstride = (int)gridDim.x;
+  auto tile_of = [&](int p, int& bm, int& bn) {
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = p & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (p >> 3);
+    constexpr int GROUP_M = T128_GROUP_M;
+    const int band = wgid / (GROUP_M * g.tiles_n);
+    const int band_rows = min(GROUP_M, g.tiles_m - band * GROUP_M);
+    const int in_band = wgid - band * GROUP_M * g.tiles_n;
+    bm = (band * GROUP_M + in_band % band_rows) * 128;
+    bn = (in_band / band_rows) * 128;
+  };
+  int p = blockIdx.x;
+  if (p >= nwg) return;
+  int bm, bn;
+  tile_of(p, bm, bn);
+  const int64_t plane_stride = (int64_t)(g.tiles_n * 4) * KB * F6_PAIR;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned voff = (unsigned)lane * 16u;
+  auto glds = [&](const unsigned char* sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+  };
+  // a half stage = three 12-KB planes = 36 pieces of 1 KB; wave w copies the three pieces of pair w of each plane.  SIX running source pointers
+  // (A and the five planes, pair w of the current tile), + 3 KB per k block: per-copy 64-bit address arithmetic made hipcc spill 344 B per lane.
+  const unsigned char* src6[6];
+  auto set_tile = [&](int tbm, int tbn) {
+    src6[0] = g.A6 + ((int64_t)(tbm / 32 + w) * KB) * F6_PAIR;
+#pragma unroll
+    for (int pl = 0; pl < 5; ++pl) src6[1 + pl] = g.W6 + (int64_t)pl * plane_stride + ((int64_t)(tbn / 32 + w) * KB) * F6_PAIR;
+  };
+  auto issue_x = [&]() {                                       // half X of the NEXT k block of the running pointers: A, planes 0, 1
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const unsigned dst = lds0 + (unsigned)(j * F6_PLANE + 3 * w * 1024); glds(src6[j], dst); glds(src6[j] + 1024, dst + 1024u); glds(src6[j] + 2048, dst + 2048u); }
+  };
+  auto issue_y = [&]() {                                       // half Y of the same k block: planes 2, 3, 4; then the pointers advance
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const unsigned dst = lds0 + (unsigned)(j * F6_PLANE + 3 * w * 1024); glds(src6[3 + j], dst); glds(src6[3 + j] + 1024, dst + 1024u); glds(src6[3 + j] + 2048, dst + 2048u); }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) src6[j] += F6_PAIR;
+  };
+  auto frag = [&](int off, int r) -> v8i {                     // volatile asm reads: hipcc may not hoist them over the previous plane's MFMAs (it did: 340 B of scratch)
+    const unsigned pb = lds0 + (unsigned)(off + (r >> 1) * F6_PAIR);
+    uint4 a; uint2 b2;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a) : "v"(pb + (unsigned)((r & 1) * 1024 + lane * 16)) : "memory");
+    asm volatile("ds_read_b64 %0, %1" : "=v"(b2) : "v"(pb + (unsigned)(2048 + (r & 1) * 512 + lane * 8)) : "memory");
+    v8i v; v[0] = (int)a.x; v[1] = (int)a.y; v[2] = (int)a.z; v[3] = (int)a.w; v[4] = (int)b2.x; v[5] = (int)b2.y; v[6] = 0; v[7] = 0;
+    return v;
+  };
+  f32x4 acc[4][4];
+  v8i fa[4], fb[4];
+  auto plane = [&](int off, int pl) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fb[t] = frag(off, 4 * wn + t);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int sb = 127 + 3 + 5 * pl;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[tm], fb[tn], acc[tm][tn], 2, 2, 0, 127, 0, sb);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+  };
+  set_tile(bm, bn);
+  issue_x();
+  int prio_ctr = (int)(blockIdx.x / (gridDim.x / 3 > 0 ? gridDim.x / 3 : 1));
+  int stage_ctr = 0;
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    const int pn = p + gstride;
+    const bool more = pn < nwg;
+    int nbm = 0, nbn = 0;
+    if (more) tile_of(pn, nbm, nbn);
+#pragma unroll 1
+    for (int kb = 0; kb < KB; ++kb) {
+      {                                                      // the CU's three workgroups take the issue priorities in turn (as the production kernel)
+        const int per = max(1, (KB * ((nwg + gstride - 1) / gstride) + 5) / 6);
+        if (stage_ctr % per == 0) { const int pr = (prio_ctr + stage_ctr / per) % 3; if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
+        ++stage_ctr;
+      }
+      const bool last = kb + 1 == KB;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // X(kb) has landed
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fa[t] = frag(0, 4 * wm + t);
+      plane(F6_PLANE, 0); plane(2 * F6_PLANE, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave is done with X
+      issue_y();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // Y(kb) has landed
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+      plane(0, 2); plane(F6_PLANE, 3); plane(2 * F6_PLANE, 4);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave is done with Y
+      if (!last) issue_x();
+    }
+    float4 ep_rs[2], ep_bv[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
+      ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
+      if (n < g.N) { ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n); if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n); }
+    }
+    {
+      char* eb = smem + w * EPI_WAVE;
+      const int c4 = (lane & 7) * 4;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int n = bn + wn * 64 + tn * 32 + c4;
+        const float4 rs = ep_rs[tn], bv = ep_bv[tn];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + l15 * 4) = acc[tm][2 * tn][e];
+            *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + (16 + l15) * 4) = acc[tm][2 * tn + 1][e];
+          }
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int r16 = it * 8 + (lane >> 3);
+            const float4 v = *reinterpret_cast<const float4*>(eb + r16 * 144 + c4 * 4);
+            const int m = bm + wm * 64 + tm * 16 + r16;
+            float4 o;
+            o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
+            if (n < g.N && m < g.M) *reinterpret_cast<float4*>(g.y + (int64_t)m * g.N + n) = o;
+          }
+        }
+      }
+    }
+    if (!more) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");     // the slices are done with
+    // the epilogue's stores are ordinary VMEM operations: they sit in the same in-order vmcnt as the Y copies issued before them
+    set_tile(nbm, nbn);
+    issue_x();
+    p = pn; bm = nbm; bn = nbn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // The double-buffered form: 256 x 128 tiles, ONE workgroup of 8 waves per CU (4 x 2 of 64 x 64 outputs), the activation fragments straight
 // from global memory into registers (one k block ahead), the five digit planes of a k block (60 KB) in one of TWO LDS buffers: every
 // wave issues its share of the next k block's plane copies (60 pieces of 1 KB: 7 or 8 per wave) at the top of a k block and then
@@ -1208,6 +1364,16 @@ int main() {      // timing of the ring kernel alone on random operand bytes (ev
       printf("double-buffered 256 x 128 form (8 waves, A fragments from global memory): %.1f us\n", ms * 5.f);
     }
   }
+  {   // the production recipe on FP6 operands: half stages through one 36-KB buffer, three workgroups per CU
+    hipFuncSetAttribute((const void*)gemm_fp6_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HS_HALF);
+    const unsigned g3 = std::min<unsigned>((M / 128) * (N / 128), 3 * gemm_grid(1 << 30));
+    for (int rep = 0; rep < 3; ++rep) {
+      float ms;
+      for (int i = 0; i < 20; ++i) gemm_fp6_h3_kernel<<<g3, 256, HS_HALF>>>(fr.f);
+      hipEventRecord(a); for (int i = 0; i < 200; ++i) gemm_fp6_h3_kernel<<<g3, 256, HS_HALF>>>(fr.f); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+      printf("half stages through one 36-KB buffer, three workgroups per CU (the production recipe): %.1f us\n", ms * 5.f);
+    }
+  }
   {   // the half-stage double-buffered transplant
     hipFuncSetAttribute((const void*)gemm_fp6_hs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F6_STAGE);
     const unsigned gh = std::min<unsigned>((M / 128) * (N / 128), 2 * gemm_grid(1 << 30));
@@ -1367,6 +1533,17 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 10; ++i) gemm_fp6_db_kernel<<<gd, 512, DB_LDS>>>(fd);
     hipEventRecord(a2); for (int i = 0; i < 100; ++i) gemm_fp6_db_kernel<<<gd, 512, DB_LDS>>>(fd); hipEventRecord(b2); hipEventSynchronize(b2); hipEventElapsedTime(&ms, a2, b2);
     printf("double-buffered 256 x 128 form: %.1f us\n", ms * 10.f);
+  }
+  {   // the production recipe on FP6 operands -> bit-identical
+    float* y3; hipMalloc(&y3, (size_t)M * N * 4); hipMemset(y3, 0, (size_t)M * N * 4);
+    GemmFp6Args f3 = f; f3.y = y3;
+    hipFuncSetAttribute((const void*)gemm_fp6_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HS_HALF);
+    const unsigned g3 = std::min<unsigned>((M / 128) * (N / 128), 3 * cus);
+    gemm_fp6_h3_kernel<<<g3, 256, HS_HALF>>>(f3);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("h3 kernel failed\n"); return 1; }
+    std::vector<float> h3v((size_t)M * N); hipMemcpy(h3v.data(), y3, h3v.size() * 4, hipMemcpyDeviceToHost);
+    size_t diff = 0; for (size_t i = 0; i < h3v.size(); ++i) diff += h3v[i] != h6[i];
+    printf("half stages through one buffer, three workgroups per CU: %zu of %zu outputs differ from the transplant's\n", diff, h3v.size());
   }
   {   // the half-stage double-buffered transplant: same products per output in the same order -> bit-identical
     float* yh; hipMalloc(&yh, (size_t)M * N * 4); hipMemset(yh, 0, (size_t)M * N * 4);
