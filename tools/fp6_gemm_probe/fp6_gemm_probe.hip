@@ -22,6 +22,7 @@ int check_launch(const char* what) { hipError_t e = hipGetLastError(); if (e != 
 #else       // -DRING_ONLY: the ring kernel alone (diagnostic builds compile in seconds instead of minutes); no comparison kernels
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <math.h>
 namespace spq {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -740,28 +741,49 @@ __global__ __launch_bounds__(256, 3) void gemm_fp6_h3_kernel(GemmFp6Args g) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) src6[j] += F6_PAIR;
   };
-  auto frag = [&](int off, int r) -> v8i {                     // volatile asm reads: hipcc may not hoist them over the previous plane's MFMAs (it did: 340 B of scratch)
-    const unsigned pb = lds0 + (unsigned)(off + (r >> 1) * F6_PAIR);
-    uint4 a; uint2 b2;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(a) : "v"(pb + (unsigned)((r & 1) * 1024 + lane * 16)) : "memory");
-    asm volatile("ds_read_b64 %0, %1" : "=v"(b2) : "v"(pb + (unsigned)(2048 + (r & 1) * 512 + lane * 8)) : "memory");
-    v8i v; v[0] = (int)a.x; v[1] = (int)a.y; v[2] = (int)a.z; v[3] = (int)a.w; v[4] = (int)b2.x; v[5] = (int)b2.y; v[6] = 0; v[7] = 0;
-    return v;
-  };
+  // ---- hand-allocated fragment registers: one asm block per plane.  v[120:143] hold the four 6-register weight operands of the plane (fixed, declared
+  // clobbered in every block, so hipcc keeps out of them), the sixteen accumulators are tied operands (in place), the four activation operands inputs.
+  typedef int v6i __attribute__((ext_vector_type(6)));
+  v6i fa[4];
   f32x4 acc[4][4];
-  v8i fa[4], fb[4];
-  auto plane = [&](int off, int pl) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) fb[t] = frag(off, 4 * wn + t);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned a16_0 = lds0 + (unsigned)(2 * wn * F6_PAIR + lane * 16), a8_0 = lds0 + (unsigned)(2 * wn * F6_PAIR + 2048 + lane * 8);
+  const int scale_a = 127;
+#define F6_MFMA(tm, tn, breg) "v_mfma_scale_f32_16x16x128_f8f6f4 %[c" #tm #tn "], %[a" #tm "], " breg ", %[c" #tm #tn "], %[sa], %[sb] op_sel_hi:[0,0,0] cbsz:2 blgp:2\n\t"
+#define F6_ROW0(tm) F6_MFMA(tm, 0, "v[120:125]") F6_MFMA(tm, 1, "v[126:131]") F6_MFMA(tm, 2, "v[132:137]") F6_MFMA(tm, 3, "v[138:143]")
+#define F6_ROW1(tm) F6_MFMA(tm, 0, "v[144:149]") F6_MFMA(tm, 1, "v[150:155]") F6_MFMA(tm, 2, "v[156:161]") F6_MFMA(tm, 3, "v[162:167]")
+#define F6_CLOB0 "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143"
+#define F6_CLOB1 "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+  // TWO fixed fragment sets (v[120:143], v[144:167]): a plane's eight reads are issued one plane ahead of its sixteen MFMAs; both sets are declared
+  // clobbered by every block, so hipcc never allocates them and their contents survive from block to block.
+  auto rd = [&](int set, int off) {
+    const unsigned a16 = a16_0 + (unsigned)off, a8 = a8_0 + (unsigned)off;
+    if (set == 0)
+      asm volatile("ds_read_b128 v[120:123], %[p16]\n\tds_read_b64 v[124:125], %[p8]\n\tds_read_b128 v[126:129], %[p16] offset:1024\n\tds_read_b64 v[130:131], %[p8] offset:512\n\t"
+                   "ds_read_b128 v[132:135], %[p16] offset:3072\n\tds_read_b64 v[136:137], %[p8] offset:3072\n\tds_read_b128 v[138:141], %[p16] offset:4096\n\tds_read_b64 v[142:143], %[p8] offset:3584"
+                   :: [p16] "v"(a16), [p8] "v"(a8) : "memory", F6_CLOB0, F6_CLOB1);
+    else
+      asm volatile("ds_read_b128 v[144:147], %[p16]\n\tds_read_b64 v[148:149], %[p8]\n\tds_read_b128 v[150:153], %[p16] offset:1024\n\tds_read_b64 v[154:155], %[p8] offset:512\n\t"
+                   "ds_read_b128 v[156:159], %[p16] offset:3072\n\tds_read_b64 v[160:161], %[p8] offset:3072\n\tds_read_b128 v[162:165], %[p16] offset:4096\n\tds_read_b64 v[166:167], %[p8] offset:3584"
+                   :: [p16] "v"(a16), [p8] "v"(a8) : "memory", F6_CLOB0, F6_CLOB1);
+  };
+#define F6_MM(ROWS, WAIT) asm volatile("s_waitcnt lgkmcnt(" #WAIT ")\n\t" ROWS(0) ROWS(1) ROWS(2) ROWS(3) \
+        : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c02] "+v"(acc[0][2]), [c03] "+v"(acc[0][3]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]), [c12] "+v"(acc[1][2]), [c13] "+v"(acc[1][3]), \
+          [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]), [c22] "+v"(acc[2][2]), [c23] "+v"(acc[2][3]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]), [c32] "+v"(acc[3][2]), [c33] "+v"(acc[3][3]) \
+        : [a0] "v"(fa[0]), [a1] "v"(fa[1]), [a2] "v"(fa[2]), [a3] "v"(fa[3]), [sa] "v"(scale_a), [sb] "v"(sb) : "memory", F6_CLOB0, F6_CLOB1)
+  auto mm = [&](int set, int pl, bool more_in_flight) {        // more_in_flight: the OTHER set's eight reads were issued after this set's
     const int sb = 127 + 3 + 5 * pl;
+    if (set == 0) { if (more_in_flight) F6_MM(F6_ROW0, 8); else F6_MM(F6_ROW0, 0); }
+    else { if (more_in_flight) F6_MM(F6_ROW1, 8); else F6_MM(F6_ROW1, 0); }
+  };
+  auto load_a = [&]() {                                        // the activation operands of the wave's four row tiles (plane 0 of the X half)
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
-        acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[tm], fb[tn], acc[tm][tn], 2, 2, 0, 127, 0, sb);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
+    for (int t = 0; t < 4; ++t) {
+      const int r = 4 * wm + t;
+      const char* pb = smem + (r >> 1) * F6_PAIR;
+      const uint4 a = *reinterpret_cast<const uint4*>(pb + (r & 1) * 1024 + lane * 16);
+      const uint2 b2 = *reinterpret_cast<const uint2*>(pb + 2048 + (r & 1) * 512 + lane * 8);
+      fa[t][0] = (int)a.x; fa[t][1] = (int)a.y; fa[t][2] = (int)a.z; fa[t][3] = (int)a.w; fa[t][4] = (int)b2.x; fa[t][5] = (int)b2.y;
+    }
   };
   set_tile(bm, bn);
   issue_x();
@@ -788,15 +810,15 @@ __global__ __launch_bounds__(256, 3) void gemm_fp6_h3_kernel(GemmFp6Args g) {
       const bool last = kb + 1 == KB;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // X(kb) has landed
       __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fa[t] = frag(0, 4 * wm + t);
-      plane(F6_PLANE, 0); plane(2 * F6_PLANE, 1);
+      load_a();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (the activation operands: compiler-managed reads; the counted waits below start from zero)
+      rd(0, F6_PLANE); rd(1, 2 * F6_PLANE); mm(0, 0, true); mm(1, 1, false);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave is done with X
       issue_y();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // Y(kb) has landed
       __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
-      plane(0, 2); plane(F6_PLANE, 3); plane(2 * F6_PLANE, 4);
+      rd(0, 0); rd(1, F6_PLANE); mm(0, 2, true); rd(0, 2 * F6_PLANE); mm(1, 3, true); mm(0, 4, false);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave is done with Y
       if (!last) issue_x();
@@ -840,6 +862,186 @@ __global__ __launch_bounds__(256, 3) void gemm_fp6_h3_kernel(GemmFp6Args g) {
     // the epilogue's stores are ordinary VMEM operations: they sit in the same in-order vmcnt as the Y copies issued before them
     set_tile(nbm, nbn);
     issue_x();
+    p = pn; bm = nbm; bn = nbn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The half-stage double buffer again (X = {A, planes 0, 1} and Y = {planes 2, 3, 4} in two 36-KB buffers, the copies of one in flight under the MFMAs of
+// the other, two workgroups per CU) -- with the hand-allocated plane blocks of the kernel above instead of hipcc's fragment handling.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_fp6_hs2_kernel(GemmFp6Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int l15 = lane & 15, q4 = lane >> 4;
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int KB = g.K / 128;
+  const int gstride = (int)gridDim.x;
+  auto tile_of = [&](int p, int& bm, int& bn) {
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = p & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (p >> 3);
+    constexpr int GROUP_M = T128_GROUP_M;
+    const int band = wgid / (GROUP_M * g.tiles_n);
+    const int band_rows = min(GROUP_M, g.tiles_m - band * GROUP_M);
+    const int in_band = wgid - band * GROUP_M * g.tiles_n;
+    bm = (band * GROUP_M + in_band % band_rows) * 128;
+    bn = (in_band / band_rows) * 128;
+  };
+  int p = blockIdx.x;
+  if (p >= nwg) return;
+  int bm, bn;
+  tile_of(p, bm, bn);
+  const int64_t plane_stride = (int64_t)(g.tiles_n * 4) * KB * F6_PAIR;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned voff = (unsigned)lane * 16u;
+  auto glds = [&](const unsigned char* sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+  };
+  // a half stage = three 12-KB planes = 36 pieces of 1 KB; wave w copies the three pieces of pair w of each plane.  SIX running source pointers
+  // (A and the five planes, pair w of the current tile), + 3 KB per k block: per-copy 64-bit address arithmetic made hipcc spill 344 B per lane.
+  const unsigned char* src6[6];
+  auto set_tile = [&](int tbm, int tbn) {
+    src6[0] = g.A6 + ((int64_t)(tbm / 32 + w) * KB) * F6_PAIR;
+#pragma unroll
+    for (int pl = 0; pl < 5; ++pl) src6[1 + pl] = g.W6 + (int64_t)pl * plane_stride + ((int64_t)(tbn / 32 + w) * KB) * F6_PAIR;
+  };
+  auto issue_x = [&]() {                                       // half X of the NEXT k block of the running pointers: A, planes 0, 1
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const unsigned dst = lds0 + (unsigned)(j * F6_PLANE + 3 * w * 1024); glds(src6[j], dst); glds(src6[j] + 1024, dst + 1024u); glds(src6[j] + 2048, dst + 2048u); }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) src6[j] += F6_PAIR;
+  };
+  auto issue_y = [&]() {                                       // half Y of the same k block: planes 2, 3, 4; then the pointers advance
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const unsigned dst = lds0 + (unsigned)(HS_HALF + j * F6_PLANE + 3 * w * 1024); glds(src6[3 + j], dst); glds(src6[3 + j] + 1024, dst + 1024u); glds(src6[3 + j] + 2048, dst + 2048u); }
+#pragma unroll
+    for (int j = 3; j < 6; ++j) src6[j] += F6_PAIR;
+  };
+  // ---- hand-allocated fragment registers: one asm block per plane.  v[120:143] hold the four 6-register weight operands of the plane (fixed, declared
+  // clobbered in every block, so hipcc keeps out of them), the sixteen accumulators are tied operands (in place), the four activation operands inputs.
+  typedef int v6i __attribute__((ext_vector_type(6)));
+  v6i fa[4];
+  f32x4 acc[4][4];
+  const unsigned a16_0 = lds0 + (unsigned)(2 * wn * F6_PAIR + lane * 16), a8_0 = lds0 + (unsigned)(2 * wn * F6_PAIR + 2048 + lane * 8);
+  const int scale_a = 127;
+#define F6_MFMA(tm, tn, breg) "v_mfma_scale_f32_16x16x128_f8f6f4 %[c" #tm #tn "], %[a" #tm "], " breg ", %[c" #tm #tn "], %[sa], %[sb] op_sel_hi:[0,0,0] cbsz:2 blgp:2\n\t"
+#define F6_ROW0(tm) F6_MFMA(tm, 0, "v[120:125]") F6_MFMA(tm, 1, "v[126:131]") F6_MFMA(tm, 2, "v[132:137]") F6_MFMA(tm, 3, "v[138:143]")
+#define F6_ROW1(tm) F6_MFMA(tm, 0, "v[144:149]") F6_MFMA(tm, 1, "v[150:155]") F6_MFMA(tm, 2, "v[156:161]") F6_MFMA(tm, 3, "v[162:167]")
+#define F6_CLOB0 "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143"
+#define F6_CLOB1 "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+  // TWO fixed fragment sets (v[120:143], v[144:167]): a plane's eight reads are issued one plane ahead of its sixteen MFMAs; both sets are declared
+  // clobbered by every block, so hipcc never allocates them and their contents survive from block to block.
+  auto rd = [&](int set, int off) {
+    const unsigned a16 = a16_0 + (unsigned)off, a8 = a8_0 + (unsigned)off;
+    if (set == 0)
+      asm volatile("ds_read_b128 v[120:123], %[p16]\n\tds_read_b64 v[124:125], %[p8]\n\tds_read_b128 v[126:129], %[p16] offset:1024\n\tds_read_b64 v[130:131], %[p8] offset:512\n\t"
+                   "ds_read_b128 v[132:135], %[p16] offset:3072\n\tds_read_b64 v[136:137], %[p8] offset:3072\n\tds_read_b128 v[138:141], %[p16] offset:4096\n\tds_read_b64 v[142:143], %[p8] offset:3584"
+                   :: [p16] "v"(a16), [p8] "v"(a8) : "memory", F6_CLOB0, F6_CLOB1);
+    else
+      asm volatile("ds_read_b128 v[144:147], %[p16]\n\tds_read_b64 v[148:149], %[p8]\n\tds_read_b128 v[150:153], %[p16] offset:1024\n\tds_read_b64 v[154:155], %[p8] offset:512\n\t"
+                   "ds_read_b128 v[156:159], %[p16] offset:3072\n\tds_read_b64 v[160:161], %[p8] offset:3072\n\tds_read_b128 v[162:165], %[p16] offset:4096\n\tds_read_b64 v[166:167], %[p8] offset:3584"
+                   :: [p16] "v"(a16), [p8] "v"(a8) : "memory", F6_CLOB0, F6_CLOB1);
+  };
+#define F6_MM(ROWS, WAIT) asm volatile("s_waitcnt lgkmcnt(" #WAIT ")\n\t" ROWS(0) ROWS(1) ROWS(2) ROWS(3) \
+        : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c02] "+v"(acc[0][2]), [c03] "+v"(acc[0][3]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]), [c12] "+v"(acc[1][2]), [c13] "+v"(acc[1][3]), \
+          [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]), [c22] "+v"(acc[2][2]), [c23] "+v"(acc[2][3]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]), [c32] "+v"(acc[3][2]), [c33] "+v"(acc[3][3]) \
+        : [a0] "v"(fa[0]), [a1] "v"(fa[1]), [a2] "v"(fa[2]), [a3] "v"(fa[3]), [sa] "v"(scale_a), [sb] "v"(sb) : "memory", F6_CLOB0, F6_CLOB1)
+  auto mm = [&](int set, int pl, bool more_in_flight) {        // more_in_flight: the OTHER set's eight reads were issued after this set's
+    const int sb = 127 + 3 + 5 * pl;
+    if (set == 0) { if (more_in_flight) F6_MM(F6_ROW0, 8); else F6_MM(F6_ROW0, 0); }
+    else { if (more_in_flight) F6_MM(F6_ROW1, 8); else F6_MM(F6_ROW1, 0); }
+  };
+  auto load_a = [&]() {                                        // the activation operands of the wave's four row tiles (plane 0 of the X half)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = 4 * wm + t;
+      const char* pb = smem + (r >> 1) * F6_PAIR;
+      const uint4 a = *reinterpret_cast<const uint4*>(pb + (r & 1) * 1024 + lane * 16);
+      const uint2 b2 = *reinterpret_cast<const uint2*>(pb + 2048 + (r & 1) * 512 + lane * 8);
+      fa[t][0] = (int)a.x; fa[t][1] = (int)a.y; fa[t][2] = (int)a.z; fa[t][3] = (int)a.w; fa[t][4] = (int)b2.x; fa[t][5] = (int)b2.y;
+    }
+  };
+  set_tile(bm, bn);
+  issue_x();
+  issue_y();
+  int prio_ctr = (int)(blockIdx.x / (gridDim.x / 2 > 0 ? gridDim.x / 2 : 1));
+  int stage_ctr = 0;
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    const int pn = p + gstride;
+    const bool more = pn < nwg;
+    int nbm = 0, nbn = 0;
+    if (more) tile_of(pn, nbm, nbn);
+#pragma unroll 1
+    for (int kb = 0; kb < KB; ++kb) {
+      {                                                      // the CU's three workgroups take the issue priorities in turn (as the production kernel)
+        const int per = max(1, (KB * ((nwg + gstride - 1) / gstride) + 5) / 6);
+        if (stage_ctr % per == 0) { const int pr = (prio_ctr + stage_ctr / per) % 2; if (pr == 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+        ++stage_ctr;
+      }
+      const bool last = kb + 1 == KB;
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");         // X(kb) has landed; the nine copies of Y(kb) may still fly
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+      load_a();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      rd(0, F6_PLANE); rd(1, 2 * F6_PLANE); mm(0, 0, true); mm(1, 1, false);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave is done with X
+      if (!last) issue_x();
+      if (!last) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Y(kb) has landed
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+      rd(0, HS_HALF); rd(1, HS_HALF + F6_PLANE); mm(0, 2, true); rd(0, HS_HALF + 2 * F6_PLANE); mm(1, 3, true); mm(0, 4, false);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");   // every wave is done with Y
+      if (!last) issue_y();
+    }
+    float4 ep_rs[2], ep_bv[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int n = bn + wn * 64 + tn * 32 + (lane & 7) * 4;
+      ep_rs[tn] = make_float4(0.f, 0.f, 0.f, 0.f); ep_bv[tn] = ep_rs[tn];
+      if (n < g.N) { ep_rs[tn] = *reinterpret_cast<const float4*>(g.rowscale + n); if (g.bias) ep_bv[tn] = *reinterpret_cast<const float4*>(g.bias + n); }
+    }
+    {
+      char* eb = smem + w * EPI_WAVE;
+      const int c4 = (lane & 7) * 4;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int n = bn + wn * 64 + tn * 32 + c4;
+        const float4 rs = ep_rs[tn], bv = ep_bv[tn];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + l15 * 4) = acc[tm][2 * tn][e];
+            *reinterpret_cast<float*>(eb + (4 * q4 + e) * 144 + (16 + l15) * 4) = acc[tm][2 * tn + 1][e];
+          }
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int r16 = it * 8 + (lane >> 3);
+            const float4 v = *reinterpret_cast<const float4*>(eb + r16 * 144 + c4 * 4);
+            const int m = bm + wm * 64 + tm * 16 + r16;
+            float4 o;
+            o.x = v.x * rs.x + bv.x; o.y = v.y * rs.y + bv.y; o.z = v.z * rs.z + bv.z; o.w = v.w * rs.w + bv.w;
+            if (n < g.N && m < g.M) *reinterpret_cast<float4*>(g.y + (int64_t)m * g.N + n) = o;
+          }
+        }
+      }
+    }
+    if (!more) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");     // the slices are done with
+    // the epilogue's stores are ordinary VMEM operations: they sit in the same in-order vmcnt as the Y copies issued before them
+    set_tile(nbm, nbn);
+    issue_x();
+    issue_y();
     p = pn; bm = nbm; bn = nbn;
   }
 }
@@ -899,29 +1101,41 @@ __global__ __launch_bounds__(512, 2) void gemm_fp6_db_kernel(GemmFp6Args g) {
       asrc16[t] = pb + (rec & 1) * 1024 + lane * 16; asrc8[t] = pb + 2048 + (rec & 1) * 512 + lane * 8;
     }
   };
-  auto issue_next = [&](int buf, v8i (&fa)[4]) {                 // the next k block of the current pointers: plane copies + activation fragments; then advance
+  typedef int v6i __attribute__((ext_vector_type(6)));
+  auto issue_next = [&](int buf, v6i (&fa)[4]) {                 // the next k block of the current pointers: plane copies + activation fragments; then advance
 #pragma unroll
     for (int i = 0; i < 8; ++i) if (w + 8 * i < 60) glds(psrc[i], lds0 + (unsigned)(buf * DB_BUF) + pdst[i]);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const uint4 a = *reinterpret_cast<const uint4*>(asrc16[t]);
       const uint2 b2 = *reinterpret_cast<const uint2*>(asrc8[t]);
-      fa[t][0] = (int)a.x; fa[t][1] = (int)a.y; fa[t][2] = (int)a.z; fa[t][3] = (int)a.w; fa[t][4] = (int)b2.x; fa[t][5] = (int)b2.y; fa[t][6] = 0; fa[t][7] = 0;
+      fa[t][0] = (int)a.x; fa[t][1] = (int)a.y; fa[t][2] = (int)a.z; fa[t][3] = (int)a.w; fa[t][4] = (int)b2.x; fa[t][5] = (int)b2.y;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) psrc[i] += F6_PAIR;
 #pragma unroll
     for (int t = 0; t < 4; ++t) { asrc16[t] += F6_PAIR; asrc8[t] += F6_PAIR; }
   };
-  auto frag = [&](unsigned off, int r) -> v8i {
-    const char* pb = smem + off + (r >> 1) * F6_PAIR;
-    const uint4 a = *reinterpret_cast<const uint4*>(pb + (r & 1) * 1024 + lane * 16);
-    const uint2 b2 = *reinterpret_cast<const uint2*>(pb + 2048 + (r & 1) * 512 + lane * 8);
-    v8i v; v[0] = (int)a.x; v[1] = (int)a.y; v[2] = (int)a.z; v[3] = (int)a.w; v[4] = (int)b2.x; v[5] = (int)b2.y; v[6] = 0; v[7] = 0;
-    return v;
-  };
   f32x4 acc[4][4];
-  v8i fa[4], fan[4], fb[4];
+  v6i fa[4], fan[4];
+  const unsigned a16_0 = lds0 + (unsigned)(2 * wn * F6_PAIR + lane * 16), a8_0 = lds0 + (unsigned)(2 * wn * F6_PAIR + 2048 + lane * 8);
+  const int scale_a = 127;
+  auto rd = [&](int set, unsigned off) {                           // the hand-allocated plane blocks of gemm_fp6_h3_kernel
+    const unsigned a16 = a16_0 + off, a8 = a8_0 + off;
+    if (set == 0)
+      asm volatile("ds_read_b128 v[120:123], %[p16]\n\tds_read_b64 v[124:125], %[p8]\n\tds_read_b128 v[126:129], %[p16] offset:1024\n\tds_read_b64 v[130:131], %[p8] offset:512\n\t"
+                   "ds_read_b128 v[132:135], %[p16] offset:3072\n\tds_read_b64 v[136:137], %[p8] offset:3072\n\tds_read_b128 v[138:141], %[p16] offset:4096\n\tds_read_b64 v[142:143], %[p8] offset:3584"
+                   :: [p16] "v"(a16), [p8] "v"(a8) : "memory", F6_CLOB0, F6_CLOB1);
+    else
+      asm volatile("ds_read_b128 v[144:147], %[p16]\n\tds_read_b64 v[148:149], %[p8]\n\tds_read_b128 v[150:153], %[p16] offset:1024\n\tds_read_b64 v[154:155], %[p8] offset:512\n\t"
+                   "ds_read_b128 v[156:159], %[p16] offset:3072\n\tds_read_b64 v[160:161], %[p8] offset:3072\n\tds_read_b128 v[162:165], %[p16] offset:4096\n\tds_read_b64 v[166:167], %[p8] offset:3584"
+                   :: [p16] "v"(a16), [p8] "v"(a8) : "memory", F6_CLOB0, F6_CLOB1);
+  };
+  auto mm = [&](int set, int pl, bool more_in_flight) {
+    const int sb = 127 + 3 + 5 * pl;
+    if (set == 0) { if (more_in_flight) F6_MM(F6_ROW0, 8); else F6_MM(F6_ROW0, 0); }
+    else { if (more_in_flight) F6_MM(F6_ROW1, 8); else F6_MM(F6_ROW1, 0); }
+  };
   int p = blockIdx.x, bm, bn;
   tile_of(p, bm, bn);
   set_tile(bm, bn);
@@ -947,18 +1161,12 @@ __global__ __launch_bounds__(512, 2) void gemm_fp6_db_kernel(GemmFp6Args g) {
       const bool last = kb + 1 == KB;
       if (last && more) set_tile(nbm, nbn);
       if (!last || more) issue_next(buf ^ 1, fan);
-#pragma unroll
-      for (int pl = 0; pl < 5; ++pl) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) fb[t] = frag((unsigned)(buf * DB_BUF + pl * F6_PLANE), 4 * wn + t);
-        const int sb = 127 + 3 + 5 * pl;
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < 4; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[tm], fb[tn], acc[tm][tn], 2, 2, 0, 127, 0, sb);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" ::: "memory");
+      {
+        const unsigned bo = (unsigned)(buf * DB_BUF);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        rd(0, bo); rd(1, bo + F6_PLANE); mm(0, 0, true); rd(0, bo + 2 * F6_PLANE); mm(1, 1, true); rd(1, bo + 3 * F6_PLANE); mm(0, 2, true);
+        rd(0, bo + 4 * F6_PLANE); mm(1, 3, true); mm(0, 4, false);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       buf ^= 1;
     }
@@ -1341,6 +1549,7 @@ int main() {      // timing of the ring kernel alone on random operand bytes (ev
   { std::vector<unsigned char> h(std::max(a_bytes, w_bytes)); unsigned x = 12345; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (unsigned char)(x >> 24); }
     hipMemcpy(dA, h.data(), a_bytes, hipMemcpyHostToDevice); hipMemcpy(dW, h.data(), w_bytes, hipMemcpyHostToDevice); }
   hipMemset(rs, 0, N * 4); hipMemset(bias, 0, N * 4); hipMemset(derr, 0, 4);
+  if (getenv("FP6_ZERO")) { hipMemset(dA, 0, a_bytes); hipMemset(dW, 0, w_bytes); printf("(all-zero operands)\n"); }      // how much of the time is the data-dependent clock?
   GemmFp6RingArgs fr{}; fr.f.A6 = dA; fr.f.W6 = dW; fr.f.rowscale = rs; fr.f.bias = bias; fr.f.y = y; fr.f.M = M; fr.f.N = N; fr.f.K = K;
   fr.f.tiles_m = M / 128; fr.f.tiles_n = N / 128; fr.err = derr;
   unsigned long long* dst = nullptr; hipMalloc(&dst, 256 * 8 * 8 * 8); hipMemset(dst, 0, 256 * 8 * 8 * 8); fr.stamps = dst;
@@ -1362,6 +1571,16 @@ int main() {      // timing of the ring kernel alone on random operand bytes (ev
       for (int i = 0; i < 20; ++i) gemm_fp6_db_kernel<<<gd, 512, DB_LDS>>>(fr.f);
       hipEventRecord(a); for (int i = 0; i < 200; ++i) gemm_fp6_db_kernel<<<gd, 512, DB_LDS>>>(fr.f); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
       printf("double-buffered 256 x 128 form (8 waves, A fragments from global memory): %.1f us\n", ms * 5.f);
+    }
+  }
+  {   // double-buffered half stages, hand-allocated plane blocks, two workgroups per CU
+    hipFuncSetAttribute((const void*)gemm_fp6_hs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F6_STAGE);
+    const unsigned g2 = std::min<unsigned>((M / 128) * (N / 128), 2 * gemm_grid(1 << 30));
+    for (int rep = 0; rep < 3; ++rep) {
+      float ms;
+      for (int i = 0; i < 20; ++i) gemm_fp6_hs2_kernel<<<g2, 256, F6_STAGE>>>(fr.f);
+      hipEventRecord(a); for (int i = 0; i < 200; ++i) gemm_fp6_hs2_kernel<<<g2, 256, F6_STAGE>>>(fr.f); hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+      printf("double-buffered half stages with hand-allocated plane blocks (two workgroups per CU): %.1f us\n", ms * 5.f);
     }
   }
   {   // the production recipe on FP6 operands: half stages through one 36-KB buffer, three workgroups per CU
@@ -1533,6 +1752,16 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 10; ++i) gemm_fp6_db_kernel<<<gd, 512, DB_LDS>>>(fd);
     hipEventRecord(a2); for (int i = 0; i < 100; ++i) gemm_fp6_db_kernel<<<gd, 512, DB_LDS>>>(fd); hipEventRecord(b2); hipEventSynchronize(b2); hipEventElapsedTime(&ms, a2, b2);
     printf("double-buffered 256 x 128 form: %.1f us\n", ms * 10.f);
+  }
+  {   // double-buffered half stages with hand-allocated plane blocks -> bit-identical
+    float* y2; hipMalloc(&y2, (size_t)M * N * 4); hipMemset(y2, 0, (size_t)M * N * 4);
+    GemmFp6Args f2 = f; f2.y = y2;
+    hipFuncSetAttribute((const void*)gemm_fp6_hs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F6_STAGE);
+    gemm_fp6_hs2_kernel<<<grid6, 256, F6_STAGE>>>(f2);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("hs2 kernel failed\n"); return 1; }
+    std::vector<float> h2v((size_t)M * N); hipMemcpy(h2v.data(), y2, h2v.size() * 4, hipMemcpyDeviceToHost);
+    size_t diff = 0; for (size_t i = 0; i < h2v.size(); ++i) diff += h2v[i] != h6[i];
+    printf("double-buffered half stages with hand-allocated plane blocks: %zu of %zu outputs differ from the transplant's\n", diff, h2v.size());
   }
   {   // the production recipe on FP6 operands -> bit-identical
     float* y3; hipMalloc(&y3, (size_t)M * N * 4); hipMemset(y3, 0, (size_t)M * N * 4);
